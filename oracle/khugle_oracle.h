@@ -1,0 +1,123 @@
+/*
+ * khugle_oracle.h -- CPU restatement of the KhuGle codec's encode/decode path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This file is the checker, never the product: only
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may build,
+ * link, load or call it.  The shipped library (image-compression_amd/csrc) must
+ * not include or link anything from this directory.
+ *
+ * Every function states the reference lines (relative to the reference checkout,
+ * directory KhuGle/) whose arithmetic and ordering it restates.  Planes are flat,
+ * row-major and contiguous here; the reference uses arrays of row pointers
+ * (KhuGleBase.cpp:188-213), which changes addressing only.
+ *
+ * Parity pinning: the whole encode path is pinned byte-for-byte by the three
+ * .comp files the reference ships (Run/cat_high.comp, Run/couple_normal.comp,
+ * Run/library_extreme.comp), the published PSNR/SSIM/size figures in
+ * Pictures/{Normal,High,Extreme}.png, and -- where oracle/_ref has been built
+ * -- by the reference's own DWT.h / Huffman.h / Writer.h / Reader.h / SSIM.h
+ * compiled unmodified (see oracle/Makefile).
+ *
+ * Rectangular images (rows != cols) are outside what the reference can round
+ * trip (its FWT2D takes one size, Compress.h:108-114).  The generalisation used
+ * here reduces exactly to the reference when rows == cols: row transforms use
+ * n = cols, column transforms n = rows, the raster width is cols, and header
+ * offset 24 holds rows, offset 28 holds cols (what Reader.h:97-110 and
+ * Main.cpp:283-285 assume).  Rectangular results are "parity unpinned".
+ */
+#ifndef KHUGLE_ORACLE_H
+#define KHUGLE_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    KHGO_OK = 0,
+    KHGO_ERR_DIMS = -1,     /* rows/cols not positive multiples of 8, or lvl not in 0..2 */
+    KHGO_ERR_CAP = -2,      /* output buffer too small */
+    KHGO_ERR_FORMAT = -3,   /* malformed .comp */
+    KHGO_ERR_RANGE = -4,    /* bit length >= 2^31 or code longer than 64 bits */
+    KHGO_ERR_NOMEM = -5
+};
+
+/* Type.h:3-28, Writer.h:9-23: the 36-byte little-endian header. */
+typedef struct khgo_header {
+    int32_t y_len, cb_len, cr_len;             /* padded bit counts */
+    int32_t rle_y_len, rle_cb_len, rle_cr_len; /* table entry counts */
+    int32_t h, w;                              /* file offsets 24 and 28 */
+    uint8_t y_pad, cb_pad, cr_pad, lvl;
+} khgo_header;
+
+/* Colorspace.h:5-23 (input u8 widened as Main.cpp:196-204). cb/cr are (h/2)x(w/2). */
+void khgo_rgb_to_ycbcr(const uint8_t *r, const uint8_t *g, const uint8_t *b, int h, int w,
+                       double *y, double *cb, double *cr);
+/* Colorspace.h:25-36 followed by the u8 truncation of Main.cpp:231-239. */
+void khgo_ycbcr_to_rgb(const double *y, const double *cb, const double *cr, int h, int w,
+                       uint8_t *r, uint8_t *g, uint8_t *b);
+
+/* DWT.h:7-60 / 62-117: 1-D lifting on n (even) samples with stride 1; tmp holds n doubles. */
+void khgo_fwt97(double *x, int n, double *tmp);
+void khgo_iwt97(double *x, int n, double *tmp);
+/* DWT.h:119-141 / 143-165 on the top-left rows x cols block of a plane with row stride. */
+int khgo_fwt2d(double *img, int stride, int rows, int cols);
+int khgo_iwt2d(double *img, int stride, int rows, int cols);
+
+/* Compress.h:108-114: level 1 then level 2 on Y (h x w) and Cb/Cr (h/2 x w/2), in place. */
+int khgo_forward_dwt(double *y, double *cb, double *cr, int h, int w);
+/* Decompress.h:274-280: level 2 then level 1, in place. */
+int khgo_inverse_dwt(double *y, double *cb, double *cr, int h, int w);
+
+/* Compress.h:143-243: per-sample divisor (step * position weight) of the luma plane
+ * (chroma == 0, plane h x w) or a chroma plane (chroma == 1, plane h/2 x w/2);
+ * h, w are always the LUMA dimensions. */
+void khgo_divisor_plane(int h, int w, int lvl, int chroma, double *div);
+/* q = (int)round(coef / divisor), Compress.h:218-219, 234-238. */
+void khgo_quantise(const double *coef, const double *div, size_t n, int32_t *q);
+/* out = q * divisor, Decompress.h:105, 120-121. */
+void khgo_dequantise(const int32_t *q, const double *div, size_t n, double *out);
+
+/* Huffman.h:110-139: (count, symbol) pairs in order of first appearance.
+ * counts/symbols must hold n entries in the worst case; returns K.
+ * faithful != 0 keeps the reference's O(n*K) linear search (for baseline timing);
+ * otherwise an O(n) dense histogram with first-index sort gives the same table. */
+long khgo_symbol_table(const int32_t *q, size_t n, int32_t *counts, int32_t *symbols, int faithful);
+
+/* Huffman.h:87-108 with libstdc++'s push_heap/pop_heap (bits/stl_heap.h) emulated
+ * move for move, then Huffman.h:57-68 code assignment.  codes[i]/lens[i] belong to
+ * symbols[i]; code bits are right-aligned, first (root) bit most significant. */
+int khgo_build_codes(const int32_t *counts, const int32_t *symbols, long k, uint64_t *codes, uint8_t *lens);
+
+/* Whole encode path (Main.cpp:196-208, Compress.h:104-408, Writer.h:43-69):
+ * planar u8 RGB -> exact .comp bytes. */
+int khgo_encode(const uint8_t *r, const uint8_t *g, const uint8_t *b, int h, int w, int lvl,
+                uint8_t *out, size_t cap, size_t *out_len, int faithful);
+/* Reader.h:5-74, Decompress.h:7-126,274-280, Colorspace.h:25-36, Main.cpp:307-315:
+ * .comp bytes -> planar u8 RGB.  r/g/b must hold rows*cols bytes (see khgo_peek). */
+int khgo_decode(const uint8_t *comp, size_t len, uint8_t *r, uint8_t *g, uint8_t *b);
+/* Reader.h:97-110: rows (offset 24) and cols (offset 28). */
+int khgo_peek(const uint8_t *comp, size_t len, khgo_header *hdr);
+
+/* Debug taps used by the parity tests. */
+int khgo_forward_planes(const uint8_t *r, const uint8_t *g, const uint8_t *b, int h, int w,
+                        double *y, double *cb, double *cr);
+int khgo_symbols(const uint8_t *r, const uint8_t *g, const uint8_t *b, int h, int w, int lvl,
+                 int32_t *qy, int32_t *qcb, int32_t *qcr);
+int khgo_decode_planes(const uint8_t *comp, size_t len, int32_t *qy, int32_t *qcb, int32_t *qcr,
+                       double *y, double *cb, double *cr);
+
+/* SSIM.h:57-72 (8x8 non-overlapping blocks, one channel). */
+double khgo_ssim(const uint8_t *a, const uint8_t *b, int width, int height);
+/* Per-block values in raster order (for the GPU kernel's per-block parity). Returns count. */
+long khgo_ssim_blocks(const uint8_t *a, const uint8_t *b, int width, int height, double *out);
+/* KhuGleBase.cpp:602-627. */
+double khgo_psnr(const uint8_t *ir, const uint8_t *ig, const uint8_t *ib,
+                 const uint8_t *or_, const uint8_t *og, const uint8_t *ob, int w, int h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
