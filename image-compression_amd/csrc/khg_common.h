@@ -1,0 +1,98 @@
+// khg_common.h -- shared definitions for the gfx950 kernels of the KhuGle codec path.
+//
+// Kernel bodies are written as sequences of barrier-separated phases.  Built by hipcc
+// they run one workgroup per body call with KHG_BARRIER() = __syncthreads().  Built
+// with -DKHG_SIM by a host compiler (tests only) the same bodies run their threads
+// one after another inside each phase, which checks indexing and arithmetic order on
+// a machine without a GPU.  The product library is only ever built without KHG_SIM.
+#pragma once
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef KHG_SIM
+#include <math.h>
+#include <string.h>
+#define KHG_DEV inline
+#define KHG_NSLOT(NT) (NT)
+#define KHG_FOR_THREADS(NT) for (int tid = 0; tid < (NT); ++tid)
+#define KHG_SLOT tid
+#define KHG_BARRIER() ((void)0)
+#define KHG_UNROLL
+static inline uint32_t khg_atomic_add(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o + v; return o; }
+static inline uint32_t khg_atomic_min(uint32_t* p, uint32_t v) { uint32_t o = *p; if (v < o) *p = v; return o; }
+static inline uint32_t khg_atomic_or(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o | v; return o; }
+static inline int khg_atomic_max_i(int* p, int v) { int o = *p; if (v > o) *p = v; return o; }
+static inline uint32_t khg_bswap32(uint32_t v) { return __builtin_bswap32(v); }
+#else
+#include <hip/hip_runtime.h>
+#define KHG_DEV __device__ __forceinline__
+#define KHG_NSLOT(NT) 1
+#define KHG_FOR_THREADS(NT) for (int tid = (int)threadIdx.x, khg_once_ = 1; khg_once_; khg_once_ = 0)
+#define KHG_SLOT 0
+#define KHG_BARRIER() __syncthreads()
+#define KHG_UNROLL _Pragma("unroll")
+__device__ __forceinline__ uint32_t khg_atomic_add(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
+__device__ __forceinline__ uint32_t khg_atomic_min(uint32_t* p, uint32_t v) { return atomicMin(p, v); }
+__device__ __forceinline__ uint32_t khg_atomic_or(uint32_t* p, uint32_t v) { return atomicOr(p, v); }
+__device__ __forceinline__ int khg_atomic_max_i(int* p, int v) { return atomicMax(p, v); }
+__device__ __forceinline__ uint32_t khg_bswap32(uint32_t v) { return __builtin_bswap32(v); }
+#endif
+
+// ---------------------------------------------------------------- constants
+
+enum {
+    KHG_NBINS = 16384,      // dense histogram over symbols [-8192, 8191]
+    KHG_SYM_BIAS = 8192,
+    KHG_CHUNK = 2048,       // symbols per bit-packing chunk (256 threads x 8)
+    KHG_MAX_CODE_BITS = 56, // code + length share one 64-bit table word
+    KHG_STRIP = 256,        // columns per transform strip (one thread per column)
+    KHG_BATCH = 16          // rows staged per strip batch
+};
+
+// Device-side result block of one encode or decode.  A kernel that detects a problem
+// stores its (negative) khg_status code in `status`; the first code written stays.
+struct KhgResult {
+    int status;            // 0 or a negative khg_status
+    int pad_;
+    uint64_t total_len;    // .comp bytes
+    int32_t bits[3];       // padded bit counts
+    int32_t k[3];          // table sizes
+    int32_t pads[3];
+    int32_t ok_to_pack;    // 1 when offsets are valid and the output fits
+};
+
+KHG_DEV void khg_set_status(int* status, int code)
+{
+    if (*status == 0) *status = code;  // racing writers all carry an error code: any of them will do
+}
+
+// Whole-sample symmetric extension of index i onto [0, n), any i (n even, >= 2).
+// The reference's boundary lines x[n-1] += 2*a*x[n-2] and x[0] += 2*a*x[1] (DWT.h:18,26,34,42)
+// equal the interior formula on this extension bit for bit: 2*a*x == a*(x + x) exactly.
+KHG_DEV int khg_reflect(int i, int n)
+{
+    if ((unsigned)i < (unsigned)n) return i;
+    int p = 2 * (n - 1);
+    i %= p;
+    if (i < 0) i += p;
+    return i < n ? i : p - i;
+}
+
+// Per-plane-type quantiser constants (Compress.h:172-209 / 223-226), computed on the host.
+struct KhgQuant {
+    double step[7];
+    double a[7];
+    double b[7];
+};
+
+// Compress.h:215-218: q = (int)round(coef / (step * (lvl >= 1 ? a*(x+y)+b : 1)))
+KHG_DEV double khg_divisor(const KhgQuant& q, int band, int x, int y, int lvl)
+{
+    double div = q.step[band];
+    if (lvl >= 1) {
+        double mul = q.a[band] * (double)(x + y) + q.b[band];
+        div = q.step[band] * mul;
+    }
+    return div;
+}

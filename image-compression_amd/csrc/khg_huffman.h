@@ -1,0 +1,493 @@
+// khg_huffman.h -- symbol table, Huffman tree/codes, and the bit-packing encoder.
+//
+//   khg_table_body : dense (count, first raster index) histogram -> (count, symbol) table in
+//                    first-appearance order (Huffman.h:110-139), then the tree and codes
+//   khg_tree_build : Huffman.h:87-108 with std::priority_queue's heap (libstdc++
+//                    bits/stl_heap.h __push_heap / __adjust_heap) reproduced move for move
+//   khg_lens_body  : bits per 2048-symbol chunk
+//   khg_scan_body  : chunk bit offsets, pads, header (Writer.h:9-23) and tables (Writer.h:34-41)
+//   khg_pack_body  : codes concatenated in raster order, MSB first (Huffman.h:76-82, Writer.h:25-32)
+#pragma once
+#include "khg_common.h"
+
+enum {
+    KHG_TREE_LDS_K = 4096,  // tables up to this size build their tree in LDS
+    KHG_TABLE_LDS_WORDS = 2 * KHG_NBINS  // 128 KiB: entry list (first, bin), later heap + node arrays
+};
+
+struct KhgTreeOut {
+    int32_t* left;     // [2*KHG_NBINS] children of internal nodes, -1 for leaves
+    int32_t* right;
+    int32_t* root;     // [1]
+};
+
+struct KhgTableArgs {
+    const uint32_t* hist_cnt;    // [3][KHG_NBINS]
+    const uint32_t* hist_first;  // [3][KHG_NBINS]
+    int32_t* tab_cnt;            // [3][KHG_NBINS] table in first-appearance order
+    int32_t* tab_sym;            // [3][KHG_NBINS]
+    int32_t* tab_k;              // [3]
+    uint64_t* codetab;           // [3][KHG_NBINS]: (len << 56) | code, indexed by symbol + 8192
+    uint32_t* big_scratch;       // [3][5 * 2 * KHG_NBINS] words, used when K > KHG_TREE_LDS_K
+    int32_t* tree_left;          // [3][2*KHG_NBINS]
+    int32_t* tree_right;         // [3][2*KHG_NBINS]
+    int32_t* tree_root;          // [3]
+    int* status;
+};
+
+struct KhgTableSmem {
+    alignas(16) uint32_t w[KHG_TABLE_LDS_WORDS];
+    uint32_t k;
+    int32_t root;
+};
+
+// Heap entry: freq in the high word, node id in the low word.  Compare (Huffman.h:25-31) looks at freq only.
+KHG_DEV bool khg_heap_comp(uint64_t l, uint64_t r) { return (uint32_t)(l >> 32) > (uint32_t)(r >> 32); }
+
+// bits/stl_heap.h __push_heap(first, holeIndex, topIndex, value, comp)
+KHG_DEV void khg_heap_sift_up(uint64_t* heap, int hole, int top, uint64_t value)
+{
+    int parent = (hole - 1) / 2;
+    while (hole > top && khg_heap_comp(heap[parent], value)) {
+        heap[hole] = heap[parent];
+        hole = parent;
+        parent = (hole - 1) / 2;
+    }
+    heap[hole] = value;
+}
+
+// priority_queue::top() + pop(): pop_heap (__pop_heap + __adjust_heap) then pop_back
+KHG_DEV uint64_t khg_heap_pop(uint64_t* heap, int& n)
+{
+    uint64_t top = heap[0];
+    if (n > 1) {
+        int len = n - 1;
+        uint64_t value = heap[len];
+        heap[len] = top;
+        int hole = 0, child = 0;
+        while (child < (len - 1) / 2) {
+            child = 2 * (child + 1);
+            if (khg_heap_comp(heap[child], heap[child - 1])) child--;
+            heap[hole] = heap[child];
+            hole = child;
+        }
+        if ((len & 1) == 0 && child == (len - 2) / 2) {
+            child = 2 * (child + 1);
+            heap[hole] = heap[child - 1];
+            hole = child - 1;
+        }
+        khg_heap_sift_up(heap, hole, 0, value);
+    }
+    n--;
+    return top;
+}
+
+// One thread.  Leaves are nodes 0..k-1 in table order; internal nodes k..2k-2 in creation order.
+// parent[] holds the parent id with bit 31 set when the node is the right ('1') child.
+KHG_DEV int khg_tree_build(const int32_t* tab_cnt, int k, uint64_t* heap, uint32_t* nfreq, uint32_t* parent,
+                           int32_t* left, int32_t* right)
+{
+    int n = 0;
+    for (int i = 0; i < k; ++i) {  // Huffman.h:91-94
+        uint32_t f = (uint32_t)tab_cnt[i];
+        nfreq[i] = f;
+        left[i] = -1;
+        right[i] = -1;
+        heap[n++] = 0;
+        khg_heap_sift_up(heap, n - 1, 0, ((uint64_t)f << 32) | (uint32_t)i);
+    }
+    int next = k;
+    while (n != 1) {  // Huffman.h:96-105
+        uint32_t r = (uint32_t)khg_heap_pop(heap, n);
+        uint32_t l = (uint32_t)khg_heap_pop(heap, n);
+        uint32_t sum = (uint32_t)(int)(nfreq[l] + nfreq[r]);
+        nfreq[next] = sum;
+        parent[l] = (uint32_t)next;
+        parent[r] = (uint32_t)next | 0x80000000u;
+        left[next] = (int32_t)l;
+        right[next] = (int32_t)r;
+        heap[n++] = 0;
+        khg_heap_sift_up(heap, n - 1, 0, ((uint64_t)sum << 32) | (uint32_t)next);
+        next++;
+    }
+    return (int)(uint32_t)heap[0];
+}
+
+// Huffman.h:57-68 from the leaf upwards: the edge nearest the root is the first (most significant) bit.
+KHG_DEV uint64_t khg_leaf_code(const uint32_t* parent, int leaf, int root, int* status)
+{
+    uint64_t code = 0;
+    int len = 0;
+    int node = leaf;
+    while (node != root) {
+        uint32_t p = parent[node];
+        if (len < 64) code |= (uint64_t)(p >> 31) << len;
+        len++;
+        node = (int)(p & 0x7FFFFFFFu);
+    }
+    if (len > KHG_MAX_CODE_BITS) {
+        khg_set_status(status, -4);
+        len = 0;
+        code = 0;
+    }
+    return ((uint64_t)len << 56) | code;
+}
+
+// bid = colour component 0..2.  256 threads.
+KHG_DEV void khg_table_body(const KhgTableArgs& a, int bid, KhgTableSmem& sh)
+{
+    const uint32_t* hc = a.hist_cnt + (size_t)bid * KHG_NBINS;
+    const uint32_t* hf = a.hist_first + (size_t)bid * KHG_NBINS;
+    int32_t* tcnt = a.tab_cnt + (size_t)bid * KHG_NBINS;
+    int32_t* tsym = a.tab_sym + (size_t)bid * KHG_NBINS;
+    uint64_t* ctab = a.codetab + (size_t)bid * KHG_NBINS;
+    int32_t* left = a.tree_left + (size_t)bid * 2 * KHG_NBINS;
+    int32_t* right = a.tree_right + (size_t)bid * 2 * KHG_NBINS;
+    uint32_t* efirst = sh.w;             // [KHG_NBINS]
+    uint32_t* ebin = sh.w + KHG_NBINS;   // [KHG_NBINS]
+
+    KHG_FOR_THREADS(256)
+    {
+        if (tid == 0) sh.k = 0;
+    }
+    KHG_BARRIER();
+    KHG_FOR_THREADS(256)
+    {
+        for (int s = tid; s < KHG_NBINS; s += 256)
+            if (hc[s]) {
+                uint32_t i = khg_atomic_add(&sh.k, 1u);
+                efirst[i] = hf[s];
+                ebin[i] = (uint32_t)s;
+            }
+    }
+    KHG_BARRIER();
+    const int k = (int)sh.k;
+    KHG_FOR_THREADS(256)
+    {
+        // rank by first raster index = position in the reference's first-appearance table
+        for (int i = tid; i < k; i += 256) {
+            uint32_t f = efirst[i];
+            int rank = 0;
+            for (int j = 0; j < k; ++j) rank += efirst[j] < f;
+            uint32_t s = ebin[i];
+            tcnt[rank] = (int32_t)hc[s];
+            tsym[rank] = (int32_t)s - KHG_SYM_BIAS;
+        }
+        if (tid == 0) a.tab_k[bid] = k;
+    }
+    KHG_BARRIER();  // table complete (global), entry list dead: LDS is reused below
+
+    uint64_t* heap;
+    uint32_t *nfreq, *parent;
+    if (k <= KHG_TREE_LDS_K) {
+        heap = (uint64_t*)sh.w;                       // [4096] u64  = 8192 words
+        nfreq = sh.w + 2 * KHG_TREE_LDS_K;            // [8192]
+        parent = sh.w + 4 * KHG_TREE_LDS_K;           // [8192]
+    } else {
+        uint32_t* g = a.big_scratch + (size_t)bid * 10 * KHG_NBINS;
+        heap = (uint64_t*)g;                          // [16384] u64
+        nfreq = g + 2 * KHG_NBINS;                    // [32768]
+        parent = g + 4 * KHG_NBINS;                   // [32768]
+    }
+    KHG_FOR_THREADS(256)
+    {
+        if (tid == 0) {
+            if (k == 0) {
+                khg_set_status(a.status, -3);
+                sh.root = 0;
+            } else {
+                sh.root = khg_tree_build(tcnt, k, heap, nfreq, parent, left, right);
+            }
+            a.tree_root[bid] = sh.root;
+        }
+    }
+    KHG_BARRIER();
+    KHG_FOR_THREADS(256)
+    {
+        const int root = sh.root;
+        for (int i = tid; i < k; i += 256) ctab[tsym[i] + KHG_SYM_BIAS] = khg_leaf_code(parent, i, root, a.status);
+    }
+}
+
+// ------------------------------------------------------------------ encoder
+
+struct KhgEncArgs {
+    const int16_t* sym[3];     // quantised planes, raster order
+    uint32_t n[3];             // symbols per plane
+    uint32_t chunk0[3];        // first chunk index of each plane
+    uint32_t nchunks;          // total
+    const uint64_t* codetab;   // [3][KHG_NBINS]
+    uint32_t* chunk_bits;      // [nchunks]
+    uint64_t* chunk_off;       // [nchunks] bit offset in the output file
+    const int32_t* tab_cnt;    // [3][KHG_NBINS]
+    const int32_t* tab_sym;
+    const int32_t* tab_k;      // [3]
+    uint8_t* out;              // .comp bytes (4-byte aligned)
+    uint64_t cap;              // bytes available at out (multiple of 4)
+    int rows, cols, lvl;
+    KhgResult* res;
+};
+
+KHG_DEV int khg_chunk_plane(const KhgEncArgs& a, uint32_t chunk)
+{
+    return chunk >= a.chunk0[2] ? 2 : chunk >= a.chunk0[1] ? 1 : 0;
+}
+
+struct KhgLensSmem {
+    uint32_t part[256];
+};
+
+// One chunk per workgroup, 8 symbols per thread.
+KHG_DEV void khg_lens_body(const KhgEncArgs& a, uint32_t chunk, KhgLensSmem& sh)
+{
+    const int p = khg_chunk_plane(a, chunk);
+    const uint64_t* ctab = a.codetab + (size_t)p * KHG_NBINS;
+    const uint32_t base = (chunk - a.chunk0[p]) * KHG_CHUNK;
+    KHG_FOR_THREADS(256)
+    {
+        uint32_t s0 = base + (uint32_t)tid * 8, bits = 0;
+        if (s0 < a.n[p]) {
+            const int16_t* q = a.sym[p] + s0;
+            for (int i = 0; i < 8; ++i) bits += (uint32_t)(ctab[q[i] + KHG_SYM_BIAS] >> 56);
+        }
+        sh.part[tid] = bits;
+    }
+    KHG_BARRIER();
+    KHG_FOR_THREADS(256)
+    {
+        if (tid < 16) {
+            uint32_t s = 0;
+            for (int i = 0; i < 16; ++i) s += sh.part[tid * 16 + i];
+            sh.part[tid * 16] = s;
+        }
+    }
+    KHG_BARRIER();
+    KHG_FOR_THREADS(256)
+    {
+        if (tid == 0) {
+            uint32_t s = 0;
+            for (int i = 0; i < 16; ++i) s += sh.part[i * 16];
+            a.chunk_bits[chunk] = s;
+        }
+    }
+}
+
+struct KhgScanSmem {
+    uint64_t psum[3][1024];
+    uint64_t base[3];     // bit offset of each plane's stream in the file
+    uint64_t table_off;   // byte offset of the tables
+    int ok;
+};
+
+KHG_DEV void khg_store_le32(uint8_t* p, int32_t v)
+{
+    uint32_t u = (uint32_t)v;
+    p[0] = (uint8_t)u;
+    p[1] = (uint8_t)(u >> 8);
+    p[2] = (uint8_t)(u >> 16);
+    p[3] = (uint8_t)(u >> 24);
+}
+
+// Single workgroup, 1024 threads.
+KHG_DEV void khg_scan_body(const KhgEncArgs& a, KhgScanSmem& sh)
+{
+    const uint32_t per = (a.nchunks + 1023) / 1024;
+    KHG_FOR_THREADS(1024)
+    {
+        uint64_t s[3] = {0, 0, 0};
+        uint32_t c0 = (uint32_t)tid * per, c1 = c0 + per < a.nchunks ? c0 + per : a.nchunks;
+        for (uint32_t c = c0; c < c1; ++c) s[khg_chunk_plane(a, c)] += a.chunk_bits[c];
+        for (int p = 0; p < 3; ++p) sh.psum[p][tid] = s[p];
+    }
+    KHG_BARRIER();
+    KHG_FOR_THREADS(1024)
+    {
+        if (tid == 0) {
+            KhgResult* res = a.res;
+            uint64_t off = 36 * 8;
+            int ok = res->status == 0;
+            for (int p = 0; p < 3; ++p) {
+                uint64_t run = 0;
+                for (int t = 0; t < 1024; ++t) {
+                    uint64_t v = sh.psum[p][t];
+                    sh.psum[p][t] = run;
+                    run += v;
+                }
+                // Compress.h:310-328: pad with '0' to a multiple of 8 bits
+                uint32_t pad = (uint32_t)((8 - (run & 7)) & 7);
+                uint64_t padded = run + pad;
+                if (padded >= ((uint64_t)1 << 31)) {  // HeaderInfo lengths are int (Type.h:5)
+                    khg_set_status(&res->status, -4);
+                    ok = 0;
+                }
+                sh.base[p] = off;
+                off += padded;
+                res->bits[p] = (int32_t)padded;
+                res->pads[p] = (int32_t)pad;
+                res->k[p] = a.tab_k[p];
+            }
+            uint64_t table_off = off >> 3;
+            uint64_t total = table_off + 8ull * ((uint64_t)a.tab_k[0] + a.tab_k[1] + a.tab_k[2]);
+            res->total_len = total;
+            if (((total + 3) & ~3ull) > a.cap) {
+                khg_set_status(&res->status, -2);
+                ok = 0;
+            }
+            sh.table_off = table_off;
+            sh.ok = ok;
+            res->ok_to_pack = ok;
+            if (ok) {
+                // Writer.h:9-23.  Offsets 24/28: rows, cols (equal for the square images the
+                // reference supports; it passes (img_height, img_width) into Type.h:18's (w, h) slots).
+                uint8_t* o = a.out;
+                khg_store_le32(o + 0, res->bits[0]);
+                khg_store_le32(o + 4, res->bits[1]);
+                khg_store_le32(o + 8, res->bits[2]);
+                khg_store_le32(o + 12, res->k[0]);
+                khg_store_le32(o + 16, res->k[1]);
+                khg_store_le32(o + 20, res->k[2]);
+                khg_store_le32(o + 24, a.rows);
+                khg_store_le32(o + 28, a.cols);
+                o[32] = (uint8_t)res->pads[0];
+                o[33] = (uint8_t)res->pads[1];
+                o[34] = (uint8_t)res->pads[2];
+                o[35] = (uint8_t)a.lvl;
+            }
+        }
+    }
+    KHG_BARRIER();
+    KHG_FOR_THREADS(1024)
+    {
+        if (sh.ok) {
+            uint32_t* out32 = (uint32_t*)a.out;
+            uint32_t c0 = (uint32_t)tid * per, c1 = c0 + per < a.nchunks ? c0 + per : a.nchunks;
+            uint64_t run[3] = {sh.psum[0][tid], sh.psum[1][tid], sh.psum[2][tid]};
+            for (uint32_t c = c0; c < c1; ++c) {
+                int p = khg_chunk_plane(a, c);
+                uint64_t off = sh.base[p] + run[p];
+                uint32_t bits = a.chunk_bits[c];
+                a.chunk_off[c] = off;
+                run[p] += bits;
+                if (bits) {  // words shared with neighbouring chunks are OR-merged by the packer: clear them
+                    out32[off >> 5] = 0;
+                    out32[(off + bits - 1) >> 5] = 0;
+                }
+            }
+            // the word holding the end of the streams also receives pad bits / the first table bytes
+            if (tid == 0) {
+                uint64_t endbit = sh.table_off * 8;
+                if (endbit > 36 * 8) out32[(endbit - 1) >> 5] = 0;
+            }
+        }
+    }
+    KHG_BARRIER();
+    KHG_FOR_THREADS(1024)
+    {
+        if (sh.ok) {
+            // Writer.h:34-41: (int32 count, int32 symbol) per entry, Y then Cb then Cr
+            uint8_t* t = a.out + sh.table_off;
+            uint32_t kk[3] = {(uint32_t)a.tab_k[0], (uint32_t)a.tab_k[1], (uint32_t)a.tab_k[2]};
+            uint32_t tot = kk[0] + kk[1] + kk[2];
+            for (uint32_t e = (uint32_t)tid; e < tot; e += 1024) {
+                int p = e >= kk[0] + kk[1] ? 2 : e >= kk[0] ? 1 : 0;
+                uint32_t i = e - (p == 2 ? kk[0] + kk[1] : p == 1 ? kk[0] : 0);
+                khg_store_le32(t + 8 * (size_t)e, a.tab_cnt[(size_t)p * KHG_NBINS + i]);
+                khg_store_le32(t + 8 * (size_t)e + 4, a.tab_sym[(size_t)p * KHG_NBINS + i]);
+            }
+        }
+    }
+}
+
+enum { KHG_PACK_WORDS = (31 + KHG_CHUNK * KHG_MAX_CODE_BITS + 31) / 32 + 2 };
+
+struct KhgPackSmem {
+    uint32_t words[KHG_PACK_WORDS];
+    uint32_t part[256];
+    uint32_t grp[16];
+};
+
+// One chunk per workgroup, 8 symbols per thread.  The chunk's bits are assembled in LDS in
+// big-endian 32-bit words aligned to the output word holding its first bit, then written out;
+// the first and last word may be shared with neighbouring chunks and are OR-merged.
+KHG_DEV void khg_pack_body(const KhgEncArgs& a, uint32_t chunk, KhgPackSmem& sh)
+{
+    if (!a.res->ok_to_pack) return;
+    const int p = khg_chunk_plane(a, chunk);
+    const uint64_t* ctab = a.codetab + (size_t)p * KHG_NBINS;
+    const uint32_t base = (chunk - a.chunk0[p]) * KHG_CHUNK;
+    const uint32_t bits = a.chunk_bits[chunk];
+    if (bits == 0) return;
+    const uint64_t off = a.chunk_off[chunk];
+    const uint32_t lead = (uint32_t)(off & 31);
+    const uint32_t nw = (lead + bits + 31) >> 5;
+
+    uint64_t code[KHG_NSLOT(256)][8];
+    KHG_FOR_THREADS(256)
+    {
+        for (uint32_t i = (uint32_t)tid; i < nw; i += 256) sh.words[i] = 0;
+        uint32_t s0 = base + (uint32_t)tid * 8, tb = 0;
+        for (int i = 0; i < 8; ++i) {
+            uint64_t c = 0;
+            if (s0 < a.n[p]) c = ctab[a.sym[p][s0 + i] + KHG_SYM_BIAS];
+            code[KHG_SLOT][i] = c;
+            tb += (uint32_t)(c >> 56);
+        }
+        sh.part[tid] = tb;
+    }
+    KHG_BARRIER();
+    KHG_FOR_THREADS(256)
+    {
+        if (tid < 16) {  // exclusive scan inside each group of 16 threads
+            uint32_t run = 0;
+            for (int i = 0; i < 16; ++i) {
+                uint32_t v = sh.part[tid * 16 + i];
+                sh.part[tid * 16 + i] = run;
+                run += v;
+            }
+            sh.grp[tid] = run;
+        }
+    }
+    KHG_BARRIER();
+    KHG_FOR_THREADS(256)
+    {
+        if (tid == 0) {
+            uint32_t run = 0;
+            for (int i = 0; i < 16; ++i) {
+                uint32_t v = sh.grp[i];
+                sh.grp[i] = run;
+                run += v;
+            }
+        }
+    }
+    KHG_BARRIER();
+    KHG_FOR_THREADS(256)
+    {
+        uint32_t pos = lead + sh.grp[tid >> 4] + sh.part[tid];
+        for (int i = 0; i < 8; ++i) {
+            uint64_t c = code[KHG_SLOT][i];
+            uint32_t len = (uint32_t)(c >> 56);
+            if (len) {
+                uint64_t v = c << (64 - len);  // left-aligned code (bits above len fall off)
+                uint32_t w = pos >> 5, sh_ = pos & 31;
+                uint32_t hi = (uint32_t)(v >> 32), lo = (uint32_t)v;
+                khg_atomic_or(&sh.words[w], hi >> sh_);
+                if (sh_ + len > 32) {
+                    uint32_t mid = sh_ ? (hi << (32 - sh_)) | (lo >> sh_) : lo;
+                    khg_atomic_or(&sh.words[w + 1], mid);
+                    if (sh_ + len > 64) khg_atomic_or(&sh.words[w + 2], lo << (32 - sh_));
+                }
+                pos += len;
+            }
+        }
+    }
+    KHG_BARRIER();
+    KHG_FOR_THREADS(256)
+    {
+        uint32_t* out32 = (uint32_t*)a.out + (off >> 5);
+        for (uint32_t i = (uint32_t)tid; i < nw; i += 256) {
+            uint32_t v = khg_bswap32(sh.words[i]);  // first stream bit = MSB of the first byte
+            if (i == 0 || i == nw - 1) khg_atomic_or(&out32[i], v);
+            else out32[i] = v;
+        }
+    }
+}

@@ -1,0 +1,182 @@
+// khg_plan.h -- host-side launch planning: workspace layout, quantiser constants, kernel
+// argument blocks and grid sizes.  Shared by the HIP host code and the test-only simulator
+// so both drive the kernel bodies identically.
+#pragma once
+#include <math.h>
+#include <string.h>
+
+#include "khg_common.h"
+#include "khg_forward.h"
+#include "khg_huffman.h"
+
+// Quantiser constants of one plane type (Compress.h:143-209 for luma, 223-226 for chroma).
+// rows/cols are the LUMA dimensions.
+static inline void khg_make_quant(int rows, int cols, int lvl, int chroma, KhgQuant* q)
+{
+    int h = rows, w = cols, h_half = h / 2, w_half = w / 2, h_qut = h / 4, w_qut = w / 4;
+    int map[7][4] = {
+        {0, h_qut, 0, w_qut},           {0, h_qut, w_qut, w_half}, {h_qut, h_half, 0, w_qut},
+        {h_qut, h_half, w_qut, w_half}, {0, h_half, w_half, w},    {h_half, h, 0, w_half},
+        {h_half, h, w_half, w}};
+    for (int index = 0; index < 7; ++index) {
+        double r = lvl == 0 ? 8 : lvl == 1 ? 10 : 12;
+        double i = 2;
+        double c = 8;
+        double f = lvl == 0 ? 23 : lvl == 1 ? 230 : 2300;
+        double tau = pow(2, r - c + i) * (1 + f / pow(2, 11));
+        double step;
+        if (index == 0) step = tau / pow(2, i);
+        else if (index == 1 || index == 2) step = tau / pow(2, 2 - 1);
+        else if (index == 3) step = tau / pow(2, 2 - 2);
+        else if (index == 4 || index == 5) step = tau / pow(2, 1 - 1);
+        else step = tau / pow(2, 1 - 2);
+        int y0 = map[index][0], y1 = map[index][1], x0 = map[index][2], x1 = map[index][3];
+        if (chroma) { y0 /= 2; y1 /= 2; x0 /= 2; x1 /= 2; }
+        int alpha = y0 + x0;
+        int beta = y1 + x1;
+        double a = 1.5 / (double)(beta - alpha);
+        double b = 0.5 - (double)(a * alpha);
+        q->step[index] = step;
+        q->a[index] = a;
+        q->b[index] = b;
+    }
+}
+
+static inline int khg_dims_ok(int rows, int cols) { return rows > 0 && cols > 0 && rows % 8 == 0 && cols % 8 == 0; }
+
+// Device workspace of one context (all pointers into device memory, or host memory in the simulator).
+struct KhgWorkspace {
+    double* ll[3];        // level-1 LL quadrants: Y (rows/2 x cols/2), Cb, Cr (rows/4 x cols/4)
+    int16_t* sym[3];      // quantised planes
+    uint32_t* hist_cnt;   // [3][KHG_NBINS]
+    uint32_t* hist_first; // [3][KHG_NBINS]
+    int32_t* tab_cnt;     // [3][KHG_NBINS]
+    int32_t* tab_sym;     // [3][KHG_NBINS]
+    int32_t* tab_k;       // [3]
+    uint64_t* codetab;    // [3][KHG_NBINS]
+    uint32_t* big_scratch;// [3][10*KHG_NBINS]
+    int32_t* tree_left;   // [3][2*KHG_NBINS]
+    int32_t* tree_right;  // [3][2*KHG_NBINS]
+    int32_t* tree_root;   // [3]
+    uint32_t* chunk_bits; // [max chunks]
+    uint64_t* chunk_off;  // [max chunks]
+    KhgResult* res;
+};
+
+static inline uint32_t khg_nchunks(uint32_t n) { return (n + KHG_CHUNK - 1) / KHG_CHUNK; }
+
+// Byte sizes of the workspace arrays for images up to rows x cols.
+struct KhgWorkspaceSizes {
+    size_t ll[3], sym[3], hist, tab, codetab, big_scratch, tree, chunk_bits, chunk_off;
+};
+static inline void khg_workspace_sizes(int rows, int cols, KhgWorkspaceSizes* s)
+{
+    size_t ny = (size_t)rows * cols, nc = ny / 4;
+    s->ll[0] = nc * sizeof(double);
+    s->ll[1] = s->ll[2] = (nc / 4) * sizeof(double);
+    s->sym[0] = ny * sizeof(int16_t);
+    s->sym[1] = s->sym[2] = nc * sizeof(int16_t);
+    s->hist = 3 * (size_t)KHG_NBINS * sizeof(uint32_t);
+    s->tab = 3 * (size_t)KHG_NBINS * sizeof(int32_t);
+    s->codetab = 3 * (size_t)KHG_NBINS * sizeof(uint64_t);
+    s->big_scratch = 3 * (size_t)10 * KHG_NBINS * sizeof(uint32_t);
+    s->tree = 3 * (size_t)2 * KHG_NBINS * sizeof(int32_t);
+    size_t nch = khg_nchunks((uint32_t)ny) + 2 * khg_nchunks((uint32_t)nc);
+    s->chunk_bits = nch * sizeof(uint32_t);
+    s->chunk_off = nch * sizeof(uint64_t);
+}
+
+// Grid of one forward-transform launch over a ph x pw plane.
+struct KhgFwdGrid {
+    int nstrip, nseg, seg_rows;
+};
+static inline KhgFwdGrid khg_fwd_grid(int ph, int pw)
+{
+    KhgFwdGrid g;
+    g.nstrip = (pw + KHG_STRIP - 1) / KHG_STRIP;
+    int nseg = 1024 / g.nstrip;            // aim for ~1024 workgroups on large planes
+    int maxseg = ph / 32 > 0 ? ph / 32 : 1; // but keep >= 32 rows per segment (8 warm-up rows each)
+    if (nseg > maxseg) nseg = maxseg;
+    if (nseg < 1) nseg = 1;
+    int seg = (ph + nseg - 1) / nseg;
+    seg = (seg + 1) & ~1;
+    g.seg_rows = seg;
+    g.nseg = (ph + seg - 1) / seg;
+    return g;
+}
+
+// Forward-transform arguments of colour component comp (0 Y, 1 Cb, 2 Cr) at level 1 or 2.
+// coef (optional) is the component's full f64 coefficient plane.
+static inline KhgFwdArgs khg_fwd_args(const KhgWorkspace& ws, const uint8_t* r, const uint8_t* g, const uint8_t* b,
+                                      int rows, int cols, int lvl, int comp, int level, double* coef,
+                                      KhgFwdGrid* grid)
+{
+    KhgFwdArgs a;
+    memset(&a, 0, sizeof a);
+    const int prow = comp ? rows / 2 : rows, pcol = comp ? cols / 2 : cols;  // component plane
+    a.r = r; a.g = g; a.b = b;
+    a.img_w = cols;
+    if (level == 1) {
+        a.ph = prow; a.pw = pcol;
+    } else {
+        a.ph = prow / 2; a.pw = pcol / 2;
+        a.src = ws.ll[comp];
+        a.src_pitch = pcol / 2;
+    }
+    a.ll = ws.ll[comp];
+    a.ll_pitch = pcol / 2;
+    a.sym = ws.sym[comp];
+    a.sym_pitch = pcol;
+    a.coef = coef;
+    a.coef_pitch = pcol;
+    a.hist_cnt = ws.hist_cnt + (size_t)comp * KHG_NBINS;
+    a.hist_first = ws.hist_first + (size_t)comp * KHG_NBINS;
+    a.status = &ws.res->status;
+    a.lvl = lvl;
+    khg_make_quant(rows, cols, lvl, comp != 0, &a.q);
+    *grid = khg_fwd_grid(a.ph, a.pw);
+    a.seg_rows = grid->seg_rows;
+    a.nstrip = grid->nstrip;
+    return a;
+}
+
+static inline KhgTableArgs khg_table_args(const KhgWorkspace& ws)
+{
+    KhgTableArgs t;
+    t.hist_cnt = ws.hist_cnt; t.hist_first = ws.hist_first;
+    t.tab_cnt = ws.tab_cnt; t.tab_sym = ws.tab_sym; t.tab_k = ws.tab_k;
+    t.codetab = ws.codetab; t.big_scratch = ws.big_scratch;
+    t.tree_left = ws.tree_left; t.tree_right = ws.tree_right; t.tree_root = ws.tree_root;
+    t.status = &ws.res->status;
+    return t;
+}
+
+static inline KhgEncArgs khg_enc_args(const KhgWorkspace& ws, int rows, int cols, int lvl, uint8_t* out, size_t cap)
+{
+    KhgEncArgs e;
+    memset(&e, 0, sizeof e);
+    uint32_t ny = (uint32_t)((size_t)rows * cols), nc = ny / 4;
+    e.n[0] = ny; e.n[1] = nc; e.n[2] = nc;
+    e.chunk0[0] = 0;
+    e.chunk0[1] = khg_nchunks(ny);
+    e.chunk0[2] = e.chunk0[1] + khg_nchunks(nc);
+    e.nchunks = e.chunk0[2] + khg_nchunks(nc);
+    for (int p = 0; p < 3; ++p) e.sym[p] = ws.sym[p];
+    e.codetab = ws.codetab;
+    e.chunk_bits = ws.chunk_bits; e.chunk_off = ws.chunk_off;
+    e.tab_cnt = ws.tab_cnt; e.tab_sym = ws.tab_sym; e.tab_k = ws.tab_k;
+    e.out = out;
+    e.cap = cap & ~(size_t)3;
+    e.rows = rows; e.cols = cols; e.lvl = lvl;
+    e.res = ws.res;
+    return e;
+}
+
+// Upper bound of the .comp size: 36-byte header, streams, three full tables; multiple of 4.
+// A Huffman code's mean length is below entropy + 1 <= log2(K) + 1 <= 15 bits for K <= 16384.
+static inline size_t khg_comp_bound_impl(int rows, int cols)
+{
+    size_t n = (size_t)rows * cols * 3 / 2;
+    size_t b = 36 + (n * 15 + 7) / 8 + 3 + 3 * (size_t)KHG_NBINS * 8;
+    return (b + 3) & ~(size_t)3;
+}

@@ -1,0 +1,417 @@
+// khugle_hip.hip -- gfx950 kernels (wrappers around the phase bodies) and the C ABI of
+// include/khugle_hip.h.  Build: see image-compression_amd/csrc/Makefile (-ffp-contract=off
+// is mandatory: the codec's f64 arithmetic must round every product and sum separately).
+#include <hip/hip_runtime.h>
+
+#include <new>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "khugle_hip.h"
+#include "khg_plan.h"
+#include "khg_synth.h"
+#ifdef KHG_WITH_DECODE
+#include "khg_decode.h"
+#include "khg_inverse.h"
+#include "khg_metrics.h"
+#endif
+
+// ------------------------------------------------------------------ kernels
+
+template <int SRC, int LEVEL>
+__global__ __launch_bounds__(256) void khg_fwd_kernel(KhgFwdArgs a)
+{
+    __shared__ KhgFwdSmem sh;
+    khg_fwd_strip_body<SRC, LEVEL>(a, (int)blockIdx.x, sh);
+}
+
+__global__ __launch_bounds__(256) void khg_table_kernel(KhgTableArgs a)
+{
+    __shared__ KhgTableSmem sh;
+    khg_table_body(a, (int)blockIdx.x, sh);
+}
+
+__global__ __launch_bounds__(256) void khg_lens_kernel(KhgEncArgs a)
+{
+    __shared__ KhgLensSmem sh;
+    khg_lens_body(a, blockIdx.x, sh);
+}
+
+__global__ __launch_bounds__(1024) void khg_scan_kernel(KhgEncArgs a)
+{
+    __shared__ KhgScanSmem sh;
+    khg_scan_body(a, sh);
+}
+
+__global__ __launch_bounds__(256) void khg_pack_kernel(KhgEncArgs a)
+{
+    __shared__ KhgPackSmem sh;
+    khg_pack_body(a, blockIdx.x, sh);
+}
+
+__global__ __launch_bounds__(256) void khg_synth_kernel(uint8_t* r, uint8_t* g, uint8_t* b, int rows, int cols,
+                                                        uint32_t seed, uint32_t index)
+{
+    size_t n = (size_t)rows * cols;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        uint32_t y = (uint32_t)(i / (size_t)cols), x = (uint32_t)(i - (size_t)y * cols);
+        khg_synth_pixel(y, x, (uint32_t)cols, seed, index, &r[i], &g[i], &b[i]);
+    }
+}
+
+#ifdef KHG_WITH_DECODE
+__global__ __launch_bounds__(256) void khg_dec_header_kernel(KhgDecArgs a)
+{
+    khg_dec_header_body(a);
+}
+
+__global__ __launch_bounds__(256) void khg_dec_tree_kernel(KhgDecArgs a)
+{
+    __shared__ KhgDecTreeSmem sh;
+    khg_dec_tree_body(a, (int)blockIdx.x, sh);
+}
+
+__global__ __launch_bounds__(256) void khg_dec_sync_kernel(KhgDecArgs a)
+{
+    __shared__ KhgDecLut sh;
+    khg_dec_sync_body(a, blockIdx.x, sh);
+}
+
+__global__ __launch_bounds__(1024) void khg_dec_scan_kernel(KhgDecArgs a)
+{
+    __shared__ KhgDecScanSmem sh;
+    khg_dec_scan_body(a, sh);
+}
+
+__global__ __launch_bounds__(256) void khg_dec_write_kernel(KhgDecArgs a)
+{
+    __shared__ KhgDecLut sh;
+    khg_dec_write_body(a, blockIdx.x, sh);
+}
+
+template <int LEVEL, int DST>
+__global__ __launch_bounds__(256) void khg_inv_kernel(KhgInvArgs a)
+{
+    __shared__ KhgInvSmem sh;
+    khg_inv_strip_body<LEVEL, DST>(a, (int)blockIdx.x, sh);
+}
+
+__global__ __launch_bounds__(256) void khg_ssim_kernel(KhgSsimArgs a)
+{
+    khg_ssim_body(a, blockIdx.x);
+}
+
+__global__ __launch_bounds__(256) void khg_sse_kernel(KhgSseArgs a)
+{
+    __shared__ KhgSseSmem sh;
+    khg_sse_body(a, blockIdx.x, gridDim.x, sh);
+}
+
+#endif  // KHG_WITH_DECODE
+
+// ------------------------------------------------------------------ context
+
+#define KHG_HIP(call)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (call);                                                                         \
+        if (e_ != hipSuccess) {                                                                         \
+            fprintf(stderr, "khugle_hip: %s failed: %s (%s:%d)\n", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return KHG_ERR_HIP;                                                                         \
+        }                                                                                               \
+    } while (0)
+
+struct khg_ctx {
+    int device;
+    int max_rows, max_cols;
+    KhgWorkspace ws;
+#ifdef KHG_WITH_DECODE
+    KhgDecWorkspace dws;
+#endif
+    void* slab;          // one device allocation carved into the workspace
+    size_t slab_bytes;
+    KhgResult* h_res;    // pinned host copy of ws.res
+    hipEvent_t done;
+    hipStream_t last_stream;
+    int pending;         // an encode/decode was enqueued and its result not yet fetched
+    // lazily allocated staging for the host-pointer entry points
+    uint8_t* stage_rgb;  // 3 planes
+    uint8_t* stage_comp;
+    size_t stage_comp_bytes;
+    double* ssim_blocks; // per-block SSIM values
+    double* h_ssim_blocks;
+    unsigned long long* sse; // [3] sums of squared errors
+};
+
+static size_t khg_align(size_t v) { return (v + 255) & ~(size_t)255; }
+
+extern "C" const char* khg_status_string(int status)
+{
+    switch (status) {
+    case KHG_OK: return "ok";
+    case KHG_ERR_DIMS: return "bad dimensions or preset";
+    case KHG_ERR_CAP: return "output buffer too small";
+    case KHG_ERR_FORMAT: return "malformed .comp data";
+    case KHG_ERR_RANGE: return "value out of representable range";
+    case KHG_ERR_NOMEM: return "out of memory";
+    case KHG_ERR_HIP: return "HIP runtime error or no device";
+    case KHG_ERR_ARG: return "bad argument";
+    default: return "unknown status";
+    }
+}
+
+extern "C" size_t khg_comp_bound(int rows, int cols)
+{
+    if (!khg_dims_ok(rows, cols)) return 0;
+    return khg_comp_bound_impl(rows, cols);
+}
+
+extern "C" int khg_ctx_create(int device, int max_rows, int max_cols, khg_ctx** out)
+{
+    if (!out || !khg_dims_ok(max_rows, max_cols)) return KHG_ERR_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return KHG_ERR_HIP;
+    KHG_HIP(hipSetDevice(device));
+    khg_ctx* c = new (std::nothrow) khg_ctx;
+    if (!c) return KHG_ERR_NOMEM;
+    memset(c, 0, sizeof *c);
+    c->device = device;
+    c->max_rows = max_rows;
+    c->max_cols = max_cols;
+
+    KhgWorkspaceSizes s;
+    khg_workspace_sizes(max_rows, max_cols, &s);
+#ifdef KHG_WITH_DECODE
+    KhgDecWorkspaceSizes ds;
+    khg_dec_workspace_sizes(max_rows, max_cols, &ds);
+#endif
+    size_t nblk = ((size_t)max_rows / 8) * ((size_t)max_cols / 8);
+    size_t total = 0;
+    auto take = [&](size_t bytes) { size_t o = total; total += khg_align(bytes); return o; };
+    size_t o_ll[3], o_sym[3];
+    for (int p = 0; p < 3; ++p) { o_ll[p] = take(s.ll[p]); o_sym[p] = take(s.sym[p]); }
+    size_t o_hc = take(s.hist), o_hf = take(s.hist), o_tc = take(s.tab), o_ts = take(s.tab), o_tk = take(64);
+    size_t o_ct = take(s.codetab), o_bs = take(s.big_scratch), o_tl = take(s.tree), o_tr = take(s.tree), o_troot = take(64);
+    size_t o_cb = take(s.chunk_bits), o_co = take(s.chunk_off), o_res = take(sizeof(KhgResult));
+#ifdef KHG_WITH_DECODE
+    size_t o_plane[3];
+    for (int p = 0; p < 3; ++p) o_plane[p] = take(ds.plane[p]);
+    size_t o_lut = take(ds.lut), o_sub = take(ds.sub), o_hdr = take(sizeof(KhgDecHeader));
+#endif
+    size_t o_ssim = take(nblk * sizeof(double)), o_sse = take(64);
+    c->slab_bytes = total;
+    if (hipMalloc(&c->slab, total) != hipSuccess) { delete c; return KHG_ERR_NOMEM; }
+    char* base = (char*)c->slab;
+    for (int p = 0; p < 3; ++p) { c->ws.ll[p] = (double*)(base + o_ll[p]); c->ws.sym[p] = (int16_t*)(base + o_sym[p]); }
+    c->ws.hist_cnt = (uint32_t*)(base + o_hc); c->ws.hist_first = (uint32_t*)(base + o_hf);
+    c->ws.tab_cnt = (int32_t*)(base + o_tc); c->ws.tab_sym = (int32_t*)(base + o_ts); c->ws.tab_k = (int32_t*)(base + o_tk);
+    c->ws.codetab = (uint64_t*)(base + o_ct); c->ws.big_scratch = (uint32_t*)(base + o_bs);
+    c->ws.tree_left = (int32_t*)(base + o_tl); c->ws.tree_right = (int32_t*)(base + o_tr); c->ws.tree_root = (int32_t*)(base + o_troot);
+    c->ws.chunk_bits = (uint32_t*)(base + o_cb); c->ws.chunk_off = (uint64_t*)(base + o_co);
+    c->ws.res = (KhgResult*)(base + o_res);
+#ifdef KHG_WITH_DECODE
+    for (int p = 0; p < 3; ++p) c->dws.plane[p] = (double*)(base + o_plane[p]);
+    c->dws.lut = (uint32_t*)(base + o_lut);
+    c->dws.sub = (KhgSubInfo*)(base + o_sub);
+    c->dws.hdr = (KhgDecHeader*)(base + o_hdr);
+#endif
+    c->ssim_blocks = (double*)(base + o_ssim);
+    c->sse = (unsigned long long*)(base + o_sse);
+    if (hipMemset(c->slab, 0, total) != hipSuccess || hipHostMalloc((void**)&c->h_res, sizeof(KhgResult)) != hipSuccess ||
+        hipEventCreateWithFlags(&c->done, hipEventDisableTiming) != hipSuccess) {
+        khg_ctx_destroy(c);
+        return KHG_ERR_HIP;
+    }
+    *out = c;
+    return KHG_OK;
+}
+
+extern "C" void khg_ctx_destroy(khg_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    if (c->slab) (void)hipFree(c->slab);
+    if (c->stage_rgb) (void)hipFree(c->stage_rgb);
+    if (c->stage_comp) (void)hipFree(c->stage_comp);
+    if (c->h_res) (void)hipHostFree(c->h_res);
+    if (c->h_ssim_blocks) (void)hipHostFree(c->h_ssim_blocks);
+    if (c->done) (void)hipEventDestroy(c->done);
+    delete c;
+}
+
+static int khg_check_image(const khg_ctx* c, int rows, int cols)
+{
+    if (!c) return KHG_ERR_ARG;
+    if (!khg_dims_ok(rows, cols) || rows > c->max_rows || cols > c->max_cols) return KHG_ERR_DIMS;
+    return KHG_OK;
+}
+
+// ------------------------------------------------------------------- encode
+
+template <int SRC, int LEVEL>
+static void khg_launch_fwd(const KhgFwdArgs& a, const KhgFwdGrid& g, hipStream_t st)
+{
+    hipLaunchKernelGGL((khg_fwd_kernel<SRC, LEVEL>), dim3(g.nstrip * g.nseg), dim3(256), 0, st, a);
+}
+
+// Colour + both DWT levels + quantiser + histograms for the three components.
+static int khg_enqueue_forward(khg_ctx* c, const uint8_t* r, const uint8_t* g, const uint8_t* b, int rows, int cols,
+                               int lvl, double* const coef[3], hipStream_t st)
+{
+    KhgWorkspace& ws = c->ws;
+    KHG_HIP(hipMemsetAsync(ws.hist_cnt, 0, 3 * KHG_NBINS * sizeof(uint32_t), st));
+    KHG_HIP(hipMemsetAsync(ws.hist_first, 0xFF, 3 * KHG_NBINS * sizeof(uint32_t), st));
+    KHG_HIP(hipMemsetAsync(ws.res, 0, sizeof(KhgResult), st));
+    KhgFwdGrid gr;
+    KhgFwdArgs a;
+    a = khg_fwd_args(ws, r, g, b, rows, cols, lvl, 0, 1, coef ? coef[0] : nullptr, &gr);
+    khg_launch_fwd<KHG_SRC_Y, 1>(a, gr, st);
+    a = khg_fwd_args(ws, r, g, b, rows, cols, lvl, 1, 1, coef ? coef[1] : nullptr, &gr);
+    khg_launch_fwd<KHG_SRC_CB, 1>(a, gr, st);
+    a = khg_fwd_args(ws, r, g, b, rows, cols, lvl, 2, 1, coef ? coef[2] : nullptr, &gr);
+    khg_launch_fwd<KHG_SRC_CR, 1>(a, gr, st);
+    for (int p = 0; p < 3; ++p) {
+        a = khg_fwd_args(ws, r, g, b, rows, cols, lvl, p, 2, coef ? coef[p] : nullptr, &gr);
+        khg_launch_fwd<KHG_SRC_PLANE, 2>(a, gr, st);
+    }
+    KHG_HIP(hipGetLastError());
+    return KHG_OK;
+}
+
+extern "C" int khg_encode_dev(khg_ctx* c, const uint8_t* d_r, const uint8_t* d_g, const uint8_t* d_b, int rows,
+                              int cols, int lvl, uint8_t* d_out, size_t cap, void* stream)
+{
+    int rc = khg_check_image(c, rows, cols);
+    if (rc) return rc;
+    if (lvl < 0 || lvl > 2) return KHG_ERR_DIMS;
+    if (!d_r || !d_g || !d_b || !d_out || ((uintptr_t)d_out & 3)) return KHG_ERR_ARG;
+    if (cap < 40) return KHG_ERR_CAP;
+    hipStream_t st = (hipStream_t)stream;
+    KHG_HIP(hipSetDevice(c->device));
+    rc = khg_enqueue_forward(c, d_r, d_g, d_b, rows, cols, lvl, nullptr, st);
+    if (rc) return rc;
+    KhgTableArgs t = khg_table_args(c->ws);
+    hipLaunchKernelGGL(khg_table_kernel, dim3(3), dim3(256), 0, st, t);
+    KhgEncArgs e = khg_enc_args(c->ws, rows, cols, lvl, d_out, cap);
+    hipLaunchKernelGGL(khg_lens_kernel, dim3(e.nchunks), dim3(256), 0, st, e);
+    hipLaunchKernelGGL(khg_scan_kernel, dim3(1), dim3(1024), 0, st, e);
+    hipLaunchKernelGGL(khg_pack_kernel, dim3(e.nchunks), dim3(256), 0, st, e);
+    KHG_HIP(hipGetLastError());
+    KHG_HIP(hipMemcpyAsync(c->h_res, c->ws.res, sizeof(KhgResult), hipMemcpyDeviceToHost, st));
+    KHG_HIP(hipEventRecord(c->done, st));
+    c->last_stream = st;
+    c->pending = 1;
+    return KHG_OK;
+}
+
+extern "C" int khg_encode_result(khg_ctx* c, size_t* out_len)
+{
+    if (!c) return KHG_ERR_ARG;
+    if (!c->pending) return KHG_ERR_ARG;
+    KHG_HIP(hipEventSynchronize(c->done));
+    if (out_len) *out_len = (size_t)c->h_res->total_len;
+    return c->h_res->status;
+}
+
+extern "C" int khg_last_status(khg_ctx* c)
+{
+    if (!c) return KHG_ERR_ARG;
+    if (!c->pending) return KHG_OK;
+    KHG_HIP(hipEventSynchronize(c->done));
+    return c->h_res->status;
+}
+
+static int khg_stage(khg_ctx* c, size_t comp_bytes)
+{
+    if (!c->stage_rgb) {
+        size_t n = (size_t)c->max_rows * c->max_cols;
+        if (hipMalloc((void**)&c->stage_rgb, 3 * n) != hipSuccess) return KHG_ERR_NOMEM;
+    }
+    if (c->stage_comp_bytes < comp_bytes) {
+        if (c->stage_comp) (void)hipFree(c->stage_comp);
+        c->stage_comp = nullptr;
+        c->stage_comp_bytes = 0;
+        if (hipMalloc((void**)&c->stage_comp, comp_bytes) != hipSuccess) return KHG_ERR_NOMEM;
+        c->stage_comp_bytes = comp_bytes;
+    }
+    return KHG_OK;
+}
+
+extern "C" int khg_encode(khg_ctx* c, const uint8_t* r, const uint8_t* g, const uint8_t* b, int rows, int cols, int lvl,
+                          uint8_t* out, size_t cap, size_t* out_len)
+{
+    int rc = khg_check_image(c, rows, cols);
+    if (rc) return rc;
+    if (!r || !g || !b || !out) return KHG_ERR_ARG;
+    KHG_HIP(hipSetDevice(c->device));
+    size_t n = (size_t)rows * cols;
+    size_t dcap = khg_comp_bound_impl(rows, cols);
+    if ((rc = khg_stage(c, dcap))) return rc;
+    uint8_t* d = c->stage_rgb;
+    KHG_HIP(hipMemcpy(d, r, n, hipMemcpyHostToDevice));
+    KHG_HIP(hipMemcpy(d + n, g, n, hipMemcpyHostToDevice));
+    KHG_HIP(hipMemcpy(d + 2 * n, b, n, hipMemcpyHostToDevice));
+    rc = khg_encode_dev(c, d, d + n, d + 2 * n, rows, cols, lvl, c->stage_comp, dcap, nullptr);
+    if (rc) return rc;
+    size_t len = 0;
+    rc = khg_encode_result(c, &len);
+    if (out_len) *out_len = len;
+    if (rc) return rc;
+    if (len > cap) return KHG_ERR_CAP;
+    KHG_HIP(hipMemcpy(out, c->stage_comp, len, hipMemcpyDeviceToHost));
+    return KHG_OK;
+}
+
+// -------------------------------------------------------------- parity taps
+
+extern "C" int khg_forward_planes_dev(khg_ctx* c, const uint8_t* d_r, const uint8_t* d_g, const uint8_t* d_b, int rows,
+                                      int cols, double* d_y, double* d_cb, double* d_cr, void* stream)
+{
+    int rc = khg_check_image(c, rows, cols);
+    if (rc) return rc;
+    if (!d_y || !d_cb || !d_cr) return KHG_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    KHG_HIP(hipSetDevice(c->device));
+    double* coef[3] = {d_y, d_cb, d_cr};
+    rc = khg_enqueue_forward(c, d_r, d_g, d_b, rows, cols, 0, coef, st);
+    if (rc) return rc;
+    KHG_HIP(hipStreamSynchronize(st));
+    return KHG_OK;
+}
+
+extern "C" int khg_symbols_dev(khg_ctx* c, const uint8_t* d_r, const uint8_t* d_g, const uint8_t* d_b, int rows,
+                               int cols, int lvl, int16_t* d_qy, int16_t* d_qcb, int16_t* d_qcr, void* stream)
+{
+    int rc = khg_check_image(c, rows, cols);
+    if (rc) return rc;
+    if (lvl < 0 || lvl > 2) return KHG_ERR_DIMS;
+    hipStream_t st = (hipStream_t)stream;
+    KHG_HIP(hipSetDevice(c->device));
+    rc = khg_enqueue_forward(c, d_r, d_g, d_b, rows, cols, lvl, nullptr, st);
+    if (rc) return rc;
+    size_t ny = (size_t)rows * cols;
+    int16_t* dst[3] = {d_qy, d_qcb, d_qcr};
+    for (int p = 0; p < 3; ++p)
+        if (dst[p])
+            KHG_HIP(hipMemcpyAsync(dst[p], c->ws.sym[p], (p ? ny / 4 : ny) * sizeof(int16_t), hipMemcpyDeviceToDevice, st));
+    KHG_HIP(hipMemcpyAsync(c->h_res, c->ws.res, sizeof(KhgResult), hipMemcpyDeviceToHost, st));
+    KHG_HIP(hipStreamSynchronize(st));
+    return c->h_res->status;
+}
+
+extern "C" int khg_synth_dev(uint8_t* d_r, uint8_t* d_g, uint8_t* d_b, int rows, int cols, uint32_t seed,
+                             uint32_t index, void* stream)
+{
+    if (!d_r || !d_g || !d_b || rows <= 0 || cols <= 0) return KHG_ERR_ARG;
+    size_t n = (size_t)rows * cols;
+    unsigned grid = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(khg_synth_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_r, d_g, d_b, rows, cols, seed, index);
+    KHG_HIP(hipGetLastError());
+    return KHG_OK;
+}
+
+#ifdef KHG_WITH_DECODE
+#include "khg_host_decode.inl"
+#endif

@@ -1,0 +1,149 @@
+"""Python harness over the C ABI: device buffers and streams come from torch, every codec
+operation runs in libkhugle_hip.so.  Counterpart of the reference application's
+LoadBMPAndCompress / LoadComp / SaveAsComp callers (Main.cpp:180-345)."""
+import ctypes as C
+
+import numpy as np
+
+from . import lib as _lib
+
+
+def _check(rc, what=""):
+    if rc != 0:
+        raise _lib.KhgError(rc, what)
+
+
+def _stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+class Codec:
+    """One khg_ctx: workspace for images up to max_rows x max_cols on one GPU."""
+
+    def __init__(self, max_rows, max_cols, device=0):
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("khugle_amd needs a HIP device (there is no CPU fallback)")
+        self.L = _lib.load()
+        self.device = device
+        self.torch = torch
+        torch.cuda.set_device(device)
+        self._ctx = C.c_void_p(0)
+        _check(self.L.khg_ctx_create(device, max_rows, max_cols, C.byref(self._ctx)), "ctx_create")
+        self.max_rows, self.max_cols = max_rows, max_cols
+
+    def close(self):
+        if self._ctx:
+            self.L.khg_ctx_destroy(self._ctx)
+            self._ctx = C.c_void_p(0)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- device-resident API (asynchronous on torch's current stream)
+    def comp_bound(self, rows, cols):
+        return self.L.khg_comp_bound(rows, cols)
+
+    def encode_dev(self, rgb, lvl, out):
+        """rgb: (3, H, W) uint8 cuda tensor; out: uint8 cuda tensor receiving the .comp bytes."""
+        assert rgb.is_cuda and rgb.dtype == self.torch.uint8 and rgb.is_contiguous() and rgb.dim() == 3
+        assert out.is_cuda and out.dtype == self.torch.uint8 and out.is_contiguous()
+        _, h, w = rgb.shape
+        _check(self.L.khg_encode_dev(self._ctx, _ptr(rgb[0]), _ptr(rgb[1]), _ptr(rgb[2]), h, w, lvl,
+                                     _ptr(out), out.numel(), _stream()), "encode_dev")
+
+    def encode_result(self):
+        n = C.c_size_t(0)
+        _check(self.L.khg_encode_result(self._ctx, C.byref(n)), "encode_result")
+        return n.value
+
+    def decode_dev(self, comp, length, rows, cols, rgb_out):
+        assert comp.is_cuda and comp.dtype == self.torch.uint8 and comp.is_contiguous()
+        assert rgb_out.is_cuda and rgb_out.dtype == self.torch.uint8 and rgb_out.is_contiguous()
+        assert tuple(rgb_out.shape) == (3, rows, cols)
+        _check(self.L.khg_decode_dev(self._ctx, _ptr(comp), length, rows, cols, _ptr(rgb_out[0]), _ptr(rgb_out[1]),
+                                     _ptr(rgb_out[2]), _stream()), "decode_dev")
+
+    def last_status(self):
+        return self.L.khg_last_status(self._ctx)
+
+    def ssim_dev(self, a, b):
+        """SSIM of two (H, W) uint8 cuda planes (the reference passes the R channel)."""
+        h, w = a.shape
+        v = C.c_double(0)
+        _check(self.L.khg_ssim_dev(self._ctx, _ptr(a), _ptr(b), w, h, C.byref(v), _stream()), "ssim")
+        return v.value
+
+    def psnr_dev(self, rgb_in, rgb_out):
+        _, h, w = rgb_in.shape
+        v = C.c_double(0)
+        _check(self.L.khg_psnr_dev(self._ctx, _ptr(rgb_in[0]), _ptr(rgb_in[1]), _ptr(rgb_in[2]), _ptr(rgb_out[0]),
+                                   _ptr(rgb_out[1]), _ptr(rgb_out[2]), w, h, C.byref(v), _stream()), "psnr")
+        return v.value
+
+    def forward_planes_dev(self, rgb):
+        t = self.torch
+        _, h, w = rgb.shape
+        y = t.empty((h, w), dtype=t.float64, device=rgb.device)
+        cb = t.empty((h // 2, w // 2), dtype=t.float64, device=rgb.device)
+        cr = t.empty((h // 2, w // 2), dtype=t.float64, device=rgb.device)
+        _check(self.L.khg_forward_planes_dev(self._ctx, _ptr(rgb[0]), _ptr(rgb[1]), _ptr(rgb[2]), h, w, _ptr(y),
+                                             _ptr(cb), _ptr(cr), _stream()), "forward_planes")
+        return y, cb, cr
+
+    def symbols_dev(self, rgb, lvl):
+        t = self.torch
+        _, h, w = rgb.shape
+        qy = t.empty((h, w), dtype=t.int16, device=rgb.device)
+        qcb = t.empty((h // 2, w // 2), dtype=t.int16, device=rgb.device)
+        qcr = t.empty((h // 2, w // 2), dtype=t.int16, device=rgb.device)
+        _check(self.L.khg_symbols_dev(self._ctx, _ptr(rgb[0]), _ptr(rgb[1]), _ptr(rgb[2]), h, w, lvl, _ptr(qy),
+                                      _ptr(qcb), _ptr(qcr), _stream()), "symbols")
+        return qy, qcb, qcr
+
+    def synth_dev(self, rows, cols, seed, index, out=None):
+        t = self.torch
+        if out is None:
+            out = t.empty((3, rows, cols), dtype=t.uint8, device="cuda:%d" % self.device)
+        _check(self.L.khg_synth_dev(_ptr(out[0]), _ptr(out[1]), _ptr(out[2]), rows, cols, seed, index, _stream()),
+               "synth")
+        return out
+
+    # ---- host-buffer API (synchronous; the library stages through its own device buffers)
+    def encode(self, rgb, lvl):
+        """rgb: (3, H, W) uint8 numpy -> bytes of the .comp file."""
+        rgb = np.ascontiguousarray(rgb, np.uint8)
+        _, h, w = rgb.shape
+        cap = self.L.khg_comp_bound(h, w)
+        if cap == 0:
+            raise _lib.KhgError(_lib.ERR_DIMS, "encode")
+        out = np.empty(cap, np.uint8)
+        n = C.c_size_t(0)
+        _check(self.L.khg_encode(self._ctx, rgb[0].ctypes.data, rgb[1].ctypes.data, rgb[2].ctypes.data, h, w, lvl,
+                                 out.ctypes.data, cap, C.byref(n)), "encode")
+        return out[:n.value].tobytes()
+
+    def decode(self, comp):
+        """bytes of a .comp file -> (3, H, W) uint8 numpy."""
+        buf = np.frombuffer(comp, np.uint8)
+        hd = peek(comp)
+        out = np.empty((3, hd.h, hd.w), np.uint8)
+        _check(self.L.khg_decode(self._ctx, buf.ctypes.data, buf.size, out[0].ctypes.data, out[1].ctypes.data,
+                                 out[2].ctypes.data), "decode")
+        return out
+
+
+def peek(comp):
+    """Header of a .comp byte string (validated)."""
+    buf = np.frombuffer(comp, np.uint8)
+    hd = _lib.Header()
+    _check(_lib.load().khg_peek(buf.ctypes.data, buf.size, C.byref(hd)), "peek")
+    return hd

@@ -1,0 +1,111 @@
+/*
+ * khugle_hip.h -- C ABI of the MI355X (gfx950) implementation of the KhuGle codec path.
+ *
+ * The reference has no FFI: its interface for this path is a set of inline C++
+ * functions called from Main.cpp on row-pointer matrices.  Each entry point below
+ * names the reference interface it stands in for.  Plain pointers and sizes only.
+ *
+ * Conventions
+ *   - return 0 (KHG_OK) on success, a negative khg_status otherwise; nothing throws.
+ *   - images are planar u8: three pointers to rows*cols bytes each, row 0 on top,
+ *     the layout CKhuGleSignal::m_Red/m_Green/m_Blue hold after ReadBmp
+ *     (KhuGleSignal.cpp:264-272) flattened row-major.
+ *   - rows and cols must be positive multiples of 8 (every transform length even at
+ *     both DWT levels of luma and chroma; the reference silently requires the same).
+ *   - "_dev" entry points take DEVICE pointers, enqueue on `stream` (a hipStream_t,
+ *     NULL = default stream) and do not synchronise; results are read with
+ *     khg_encode_result / khg_last_status.  The others take HOST pointers and are
+ *     synchronous.  A context is bound to one device and serialises its own work;
+ *     use one context per host thread / per frame in flight.
+ *   - no entry point falls back to the CPU: without a usable HIP device every call
+ *     returns KHG_ERR_HIP.
+ */
+#ifndef KHUGLE_HIP_H
+#define KHUGLE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum khg_status {
+    KHG_OK = 0,
+    KHG_ERR_DIMS = -1,      /* rows/cols not positive multiples of 8, above the context's limits, or lvl not 0..2 */
+    KHG_ERR_CAP = -2,       /* output buffer too small (khg_comp_bound gives a safe size) */
+    KHG_ERR_FORMAT = -3,    /* malformed .comp (lengths, pads, table sizes inconsistent with the buffer) */
+    KHG_ERR_RANGE = -4,     /* a plane's stream reaches 2^31 bits (header fields are int, Type.h:5),
+                               a symbol leaves [-8192, 8191], or a code exceeds 56 bits */
+    KHG_ERR_NOMEM = -5,
+    KHG_ERR_HIP = -6,       /* no device / HIP runtime error */
+    KHG_ERR_ARG = -7
+} khg_status;
+
+typedef struct khg_ctx khg_ctx;
+
+/* 36-byte header of a .comp file: HeaderInfo, Type.h:3-28, as laid out by WriteHeader, Writer.h:9-23. */
+typedef struct khg_header {
+    int32_t y_len, cb_len, cr_len;             /* padded bit counts */
+    int32_t rle_y_len, rle_cb_len, rle_cr_len; /* symbol-table entry counts */
+    int32_t h, w;                              /* file offsets 24 and 28: rows, cols */
+    uint8_t y_pad, cb_pad, cr_pad, lvl;
+} khg_header;
+
+/* Workspace for images up to max_rows x max_cols on HIP device `device`. */
+int khg_ctx_create(int device, int max_rows, int max_cols, khg_ctx **out);
+void khg_ctx_destroy(khg_ctx *ctx);
+const char *khg_status_string(int status);
+
+/* Upper bound of the .comp size for a rows x cols image (multiple of 4). */
+size_t khg_comp_bound(int rows, int cols);
+
+/* ---- encode: LoadBMPAndCompress's codec part (Main.cpp:196-208): u8 -> double copy,
+ * RGB2YCbCr (Colorspace.h:5-23), CompressImage (Compress.h:104-408, without its GUI
+ * visualisation images) and the byte layout WriteAll (Writer.h:43-69) puts on disk.
+ * `out` receives exactly the bytes of the .comp file.  lvl: 0 Normal, 1 High, 2 Extreme. */
+int khg_encode(khg_ctx *ctx, const uint8_t *r, const uint8_t *g, const uint8_t *b, int rows, int cols, int lvl,
+               uint8_t *out, size_t cap, size_t *out_len);
+int khg_encode_dev(khg_ctx *ctx, const uint8_t *d_r, const uint8_t *d_g, const uint8_t *d_b, int rows, int cols,
+                   int lvl, uint8_t *d_out, size_t cap, void *stream);
+/* Waits for the context's last encode and returns its status and .comp length. */
+int khg_encode_result(khg_ctx *ctx, size_t *out_len);
+
+/* ---- decode: LoadComp's codec part (Main.cpp:283-315): MeasureImageSize (Reader.h:97-110),
+ * ReadAll (Reader.h:56-74), DecompressImage (Decompress.h:7-126, 274-280, visualize=false),
+ * YCbCr2RGB (Colorspace.h:25-36) and the double -> u8 truncation of Main.cpp:307-315. */
+int khg_peek(const uint8_t *comp, size_t len, khg_header *hdr);  /* host bytes; validates the header */
+int khg_decode(khg_ctx *ctx, const uint8_t *comp, size_t len, uint8_t *r, uint8_t *g, uint8_t *b);
+/* rows/cols are what the caller expects the file to hold (checked against the header on the device). */
+int khg_decode_dev(khg_ctx *ctx, const uint8_t *d_comp, size_t len, int rows, int cols,
+                   uint8_t *d_r, uint8_t *d_g, uint8_t *d_b, void *stream);
+/* Waits for the context's last enqueued work and returns its device-side status. */
+int khg_last_status(khg_ctx *ctx);
+
+/* ---- quality metrics: ComputeSSIM (SSIM.h:57-72; the application passes the R channel only,
+ * Main.cpp:250-253) and GetPsnr (KhuGleBase.cpp:613-627).  Device planes, synchronous result.
+ * Per-block SSIM values are bit-exact; *ssim is their sum in raster order divided by the count. */
+int khg_ssim_dev(khg_ctx *ctx, const uint8_t *d_a, const uint8_t *d_b, int width, int height, double *ssim,
+                 void *stream);
+int khg_psnr_dev(khg_ctx *ctx, const uint8_t *d_ir, const uint8_t *d_ig, const uint8_t *d_ib,
+                 const uint8_t *d_or, const uint8_t *d_og, const uint8_t *d_ob, int width, int height, double *psnr,
+                 void *stream);
+
+/* ---- parity taps (device pointers, synchronous).  Any output pointer may be NULL.
+ * khg_forward_planes_dev: Y/Cb/Cr after the two FWT2D levels (Compress.h:108-114), f64, row-major.
+ * khg_symbols_dev: the quantised planes (Compress.h:165-243) as int16, row-major.
+ * khg_tables_dev: the (count, symbol) tables (Huffman.h:110-139) of the context's last encode. */
+int khg_forward_planes_dev(khg_ctx *ctx, const uint8_t *d_r, const uint8_t *d_g, const uint8_t *d_b, int rows,
+                           int cols, double *d_y, double *d_cb, double *d_cr, void *stream);
+int khg_symbols_dev(khg_ctx *ctx, const uint8_t *d_r, const uint8_t *d_g, const uint8_t *d_b, int rows, int cols,
+                    int lvl, int16_t *d_qy, int16_t *d_qcb, int16_t *d_qcr, void *stream);
+
+/* ---- synthetic frames for benchmarks: deterministic integer arithmetic, identical to
+ * khugle_amd.synth.synth_frame on the host.  Device planes. */
+int khg_synth_dev(uint8_t *d_r, uint8_t *d_g, uint8_t *d_b, int rows, int cols, uint32_t seed, uint32_t index,
+                  void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,101 @@
+// khg_sim.cpp -- TEST-ONLY sequential simulation of the HIP kernel bodies.
+//
+// Compiles image-compression_amd/csrc/*.h with -DKHG_SIM: every workgroup body runs its
+// threads one after another inside each barrier-separated phase, on host memory.  This
+// checks indexing, arithmetic order and the launch plan on a machine without a GPU; it
+// is never linked into, loaded by or used as a fallback for the product library.
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#define KHG_SIM 1
+#include "khg_plan.h"
+#include "khg_synth.h"
+
+namespace {
+
+struct SimWs {
+    KhgWorkspace ws;
+    std::vector<std::vector<char>> bufs;
+    template <class T> T* alloc(size_t bytes) {
+        bufs.emplace_back(bytes + 64, 0);
+        return reinterpret_cast<T*>(bufs.back().data());
+    }
+    SimWs(int rows, int cols) {
+        KhgWorkspaceSizes s;
+        khg_workspace_sizes(rows, cols, &s);
+        for (int p = 0; p < 3; ++p) { ws.ll[p] = alloc<double>(s.ll[p]); ws.sym[p] = alloc<int16_t>(s.sym[p]); }
+        ws.hist_cnt = alloc<uint32_t>(s.hist); ws.hist_first = alloc<uint32_t>(s.hist);
+        ws.tab_cnt = alloc<int32_t>(s.tab); ws.tab_sym = alloc<int32_t>(s.tab); ws.tab_k = alloc<int32_t>(16);
+        ws.codetab = alloc<uint64_t>(s.codetab); ws.big_scratch = alloc<uint32_t>(s.big_scratch);
+        ws.tree_left = alloc<int32_t>(s.tree); ws.tree_right = alloc<int32_t>(s.tree); ws.tree_root = alloc<int32_t>(16);
+        ws.chunk_bits = alloc<uint32_t>(s.chunk_bits); ws.chunk_off = alloc<uint64_t>(s.chunk_off);
+        ws.res = alloc<KhgResult>(sizeof(KhgResult));
+    }
+};
+
+template <int SRC, int LEVEL>
+void run_fwd(const KhgFwdArgs& a, const KhgFwdGrid& g) {
+    KhgFwdSmem* sh = new KhgFwdSmem;
+    for (int bid = 0; bid < g.nstrip * g.nseg; ++bid) khg_fwd_strip_body<SRC, LEVEL>(a, bid, *sh);
+    delete sh;
+}
+
+void forward_all(SimWs& S, const uint8_t* r, const uint8_t* g, const uint8_t* b, int rows, int cols, int lvl,
+                 double* const coef[3]) {
+    KhgWorkspace& ws = S.ws;
+    memset(ws.hist_cnt, 0, 3 * KHG_NBINS * 4);
+    memset(ws.hist_first, 0xFF, 3 * KHG_NBINS * 4);
+    memset(ws.res, 0, sizeof(KhgResult));
+    KhgFwdGrid gr;
+    KhgFwdArgs a;
+    a = khg_fwd_args(ws, r, g, b, rows, cols, lvl, 0, 1, coef ? coef[0] : nullptr, &gr); run_fwd<KHG_SRC_Y, 1>(a, gr);
+    a = khg_fwd_args(ws, r, g, b, rows, cols, lvl, 1, 1, coef ? coef[1] : nullptr, &gr); run_fwd<KHG_SRC_CB, 1>(a, gr);
+    a = khg_fwd_args(ws, r, g, b, rows, cols, lvl, 2, 1, coef ? coef[2] : nullptr, &gr); run_fwd<KHG_SRC_CR, 1>(a, gr);
+    for (int c = 0; c < 3; ++c) {
+        a = khg_fwd_args(ws, r, g, b, rows, cols, lvl, c, 2, coef ? coef[c] : nullptr, &gr);
+        run_fwd<KHG_SRC_PLANE, 2>(a, gr);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int khgsim_forward(const uint8_t* r, const uint8_t* g, const uint8_t* b, int rows, int cols, int lvl,
+                   double* y, double* cb, double* cr, int16_t* qy, int16_t* qcb, int16_t* qcr) {
+    if (!khg_dims_ok(rows, cols)) return -1;
+    SimWs S(rows, cols);
+    double* coef[3] = {y, cb, cr};
+    forward_all(S, r, g, b, rows, cols, lvl, coef);
+    size_t ny = (size_t)rows * cols;
+    if (qy) memcpy(qy, S.ws.sym[0], ny * 2);
+    if (qcb) memcpy(qcb, S.ws.sym[1], ny / 4 * 2);
+    if (qcr) memcpy(qcr, S.ws.sym[2], ny / 4 * 2);
+    return S.ws.res->status;
+}
+
+int khgsim_encode(const uint8_t* r, const uint8_t* g, const uint8_t* b, int rows, int cols, int lvl,
+                  uint8_t* out, size_t cap, size_t* out_len) {
+    if (!khg_dims_ok(rows, cols) || lvl < 0 || lvl > 2) return -1;
+    SimWs S(rows, cols);
+    forward_all(S, r, g, b, rows, cols, lvl, nullptr);
+    KhgTableArgs t = khg_table_args(S.ws);
+    KhgTableSmem* tsh = new KhgTableSmem;
+    for (int p = 0; p < 3; ++p) khg_table_body(t, p, *tsh);
+    delete tsh;
+    KhgEncArgs e = khg_enc_args(S.ws, rows, cols, lvl, out, cap);
+    KhgLensSmem lsh;
+    for (uint32_t c = 0; c < e.nchunks; ++c) khg_lens_body(e, c, lsh);
+    KhgScanSmem* ssh = new KhgScanSmem;
+    khg_scan_body(e, *ssh);
+    delete ssh;
+    KhgPackSmem* psh = new KhgPackSmem;
+    for (uint32_t c = 0; c < e.nchunks; ++c) khg_pack_body(e, c, *psh);
+    delete psh;
+    if (out_len) *out_len = (size_t)S.ws.res->total_len;
+    return S.ws.res->status;
+}
+
+}  // extern "C"
