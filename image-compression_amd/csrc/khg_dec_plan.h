@@ -1,0 +1,86 @@
+// khg_dec_plan.h -- host-side launch planning of the decode path (shared by the HIP host
+// code and the test-only simulator).
+#pragma once
+#include "khg_plan.h"
+#include "khg_decode.h"
+#include "khg_inverse.h"
+#include "khg_metrics.h"
+
+static inline KhgDecArgs khg_dec_args(const KhgWorkspace& ws, const KhgDecWorkspace& dws, const uint8_t* comp,
+                                      size_t len, int rows, int cols)
+{
+    KhgDecArgs d;
+    memset(&d, 0, sizeof d);
+    d.comp = comp;
+    d.len = len;
+    d.rows = rows;
+    d.cols = cols;
+    d.hdr = dws.hdr;
+    d.res = ws.res;
+    d.tab_cnt = ws.tab_cnt; d.tab_sym = ws.tab_sym;
+    d.tree_left = ws.tree_left; d.tree_right = ws.tree_right; d.tree_root = ws.tree_root;
+    d.big_scratch = ws.big_scratch;
+    d.lut = dws.lut;
+    uint32_t ny = (uint32_t)((size_t)rows * cols), nc = ny / 4;
+    d.n[0] = ny; d.n[1] = nc; d.n[2] = nc;
+    uint32_t blk = 0;
+    for (int p = 0; p < 3; ++p) {
+        d.blk0[p] = blk;
+        d.sub0[p] = blk * KHG_DEC_BLOCK;
+        blk += (khg_max_subs(d.n[p]) + KHG_DEC_BLOCK - 1) / KHG_DEC_BLOCK;
+        if (blk == d.blk0[p]) blk++;  // at least one workgroup per plane
+        d.sym[p] = ws.sym[p];
+    }
+    d.nblocks = blk;
+    d.arrive[0] = dws.lut + 3 * KHG_LUT_SIZE;
+    d.arrive[1] = d.arrive[0] + blk;
+    d.mismatch = d.arrive[1] + blk;
+    d.sub = dws.sub;
+    d.pass = 0;
+    return d;
+}
+
+// Grid of one inverse-transform launch over a ph x pw plane.
+static inline KhgFwdGrid khg_inv_grid(int ph, int pw)
+{
+    KhgFwdGrid g;
+    g.nstrip = (pw + KHG_ISTRIP - 1) / KHG_ISTRIP;
+    int nseg = 1024 / g.nstrip;
+    int maxseg = ph / 32 > 0 ? ph / 32 : 1;
+    if (nseg > maxseg) nseg = maxseg;
+    if (nseg < 1) nseg = 1;
+    int seg = (ph + nseg - 1) / nseg;
+    seg = (seg + 1) & ~1;
+    g.seg_rows = seg;
+    g.nseg = (ph + seg - 1) / seg;
+    return g;
+}
+
+// Inverse-transform arguments of colour component comp at level 2 (into the LL buffer) or
+// level 1 (into the component's f64 plane).
+static inline KhgInvArgs khg_inv_args(const KhgWorkspace& ws, const KhgDecWorkspace& dws, int rows, int cols,
+                                      int comp, int level, KhgFwdGrid* grid)
+{
+    KhgInvArgs a;
+    memset(&a, 0, sizeof a);
+    const int prow = comp ? rows / 2 : rows, pcol = comp ? cols / 2 : cols;
+    a.sym = ws.sym[comp];
+    a.sym_pitch = pcol;
+    a.ll = ws.ll[comp];
+    a.ll_pitch = pcol / 2;
+    if (level == 2) {
+        a.ph = prow / 2; a.pw = pcol / 2;
+        a.dst = ws.ll[comp];
+        a.dst_pitch = pcol / 2;
+    } else {
+        a.ph = prow; a.pw = pcol;
+        a.dst = dws.plane[comp];
+        a.dst_pitch = pcol;
+    }
+    a.hdr = dws.hdr;
+    for (int lvl = 0; lvl < 3; ++lvl) khg_make_quant(rows, cols, lvl, comp != 0, &a.q[lvl]);
+    *grid = khg_inv_grid(a.ph, a.pw);
+    a.seg_rows = grid->seg_rows;
+    a.nstrip = grid->nstrip;
+    return a;
+}

@@ -1,0 +1,221 @@
+// khg_host_decode.inl -- host side of the decode path and the quality metrics
+// (included by khugle_hip.hip).
+
+__global__ __launch_bounds__(256) void khg_rgb_kernel(KhgRgbArgs a)
+{
+    khg_rgb_body(a, blockIdx.x, gridDim.x);
+}
+
+extern "C" int khg_peek(const uint8_t* comp, size_t len, khg_header* hdr)
+{
+    if (!comp || !hdr) return KHG_ERR_ARG;
+    if (len < 36) return KHG_ERR_FORMAT;
+    auto rd = [&](size_t o) {
+        return (int32_t)((uint32_t)comp[o] | ((uint32_t)comp[o + 1] << 8) | ((uint32_t)comp[o + 2] << 16) |
+                         ((uint32_t)comp[o + 3] << 24));
+    };
+    // Reader.h:5-23
+    hdr->y_len = rd(0); hdr->cb_len = rd(4); hdr->cr_len = rd(8);
+    hdr->rle_y_len = rd(12); hdr->rle_cb_len = rd(16); hdr->rle_cr_len = rd(20);
+    hdr->h = rd(24); hdr->w = rd(28);
+    hdr->y_pad = comp[32]; hdr->cb_pad = comp[33]; hdr->cr_pad = comp[34]; hdr->lvl = comp[35];
+    if (!khg_dims_ok(hdr->h, hdr->w) || hdr->lvl > 2) return KHG_ERR_FORMAT;
+    const int32_t lens[3] = {hdr->y_len, hdr->cb_len, hdr->cr_len};
+    const int32_t ks[3] = {hdr->rle_y_len, hdr->rle_cb_len, hdr->rle_cr_len};
+    const uint8_t pads[3] = {hdr->y_pad, hdr->cb_pad, hdr->cr_pad};
+    uint64_t need = 36;
+    for (int p = 0; p < 3; ++p) {
+        if (lens[p] < 0 || (lens[p] & 7) || pads[p] > 7 || pads[p] > lens[p]) return KHG_ERR_FORMAT;
+        if (ks[p] < 1) return KHG_ERR_FORMAT;
+        need += (uint64_t)(lens[p] >> 3) + 8ull * (uint64_t)ks[p];
+    }
+    if (need > len) return KHG_ERR_FORMAT;
+    return KHG_OK;
+}
+
+static void khg_launch_sync_pass(const KhgDecArgs& d, int pass, hipStream_t st)
+{
+    KhgDecArgs a = d;
+    a.pass = pass;
+    hipLaunchKernelGGL(khg_dec_sync_kernel, dim3(a.nblocks), dim3(256), 0, st, a);
+}
+
+// Everything after the subsequence starts are known: symbols, inverse transforms, colour.
+static int khg_enqueue_decode_tail(khg_ctx* c, const KhgDecodeCall& call)
+{
+    hipStream_t st = call.st;
+    const KhgDecArgs& d = call.d;
+    hipLaunchKernelGGL(khg_dec_write_kernel, dim3(d.nblocks), dim3(256), 0, st, d);
+    KhgFwdGrid gr;
+    for (int p = 0; p < 3; ++p) {  // Decompress.h:274-276
+        KhgInvArgs a = khg_inv_args(c->ws, c->dws, call.rows, call.cols, p, 2, &gr);
+        hipLaunchKernelGGL((khg_inv_kernel<2>), dim3(gr.nstrip * gr.nseg), dim3(256), 0, st, a);
+    }
+    for (int p = 0; p < 3; ++p) {  // Decompress.h:278-280
+        KhgInvArgs a = khg_inv_args(c->ws, c->dws, call.rows, call.cols, p, 1, &gr);
+        hipLaunchKernelGGL((khg_inv_kernel<1>), dim3(gr.nstrip * gr.nseg), dim3(256), 0, st, a);
+    }
+    KhgRgbArgs ra;
+    ra.y = c->dws.plane[0]; ra.cb = c->dws.plane[1]; ra.cr = c->dws.plane[2];
+    ra.r = call.r; ra.g = call.g; ra.b = call.b;
+    ra.rows = call.rows; ra.cols = call.cols;
+    size_t quads = (size_t)call.rows * call.cols / 4;
+    unsigned grid = (unsigned)((quads + 255) / 256 < 8192 ? (quads + 255) / 256 : 8192);
+    hipLaunchKernelGGL(khg_rgb_kernel, dim3(grid), dim3(256), 0, st, ra);
+    KHG_HIP(hipGetLastError());
+    KHG_HIP(hipMemcpyAsync(c->h_res, c->ws.res, sizeof(KhgResult), hipMemcpyDeviceToHost, st));
+    KHG_HIP(hipEventRecord(c->done, st));
+    return KHG_OK;
+}
+
+extern "C" int khg_decode_dev(khg_ctx* c, const uint8_t* d_comp, size_t len, int rows, int cols, uint8_t* d_r,
+                              uint8_t* d_g, uint8_t* d_b, void* stream)
+{
+    int rc = khg_check_image(c, rows, cols);
+    if (rc) return rc;
+    if (!d_comp || !d_r || !d_g || !d_b || ((uintptr_t)d_comp & 3) || ((uintptr_t)d_r & 3) || ((uintptr_t)d_g & 3) ||
+        ((uintptr_t)d_b & 3))
+        return KHG_ERR_ARG;
+    if (len < 36 + 24) return KHG_ERR_FORMAT;
+    hipStream_t st = (hipStream_t)stream;
+    KHG_HIP(hipSetDevice(c->device));
+    KhgDecodeCall& call = c->dec_call;
+    call.d = khg_dec_args(c->ws, c->dws, d_comp, len, rows, cols);
+    call.r = d_r; call.g = d_g; call.b = d_b;
+    call.rows = rows; call.cols = cols;
+    call.st = st;
+    KHG_HIP(hipMemsetAsync(c->ws.res, 0, sizeof(KhgResult), st));
+    hipLaunchKernelGGL(khg_dec_header_kernel, dim3(1), dim3(256), 0, st, call.d);
+    hipLaunchKernelGGL(khg_dec_tree_kernel, dim3(3), dim3(256), 0, st, call.d);
+    khg_launch_sync_pass(call.d, 0, st);
+    khg_launch_sync_pass(call.d, 1, st);
+    hipLaunchKernelGGL(khg_dec_scan_kernel, dim3(1), dim3(1024), 0, st, call.d);
+    rc = khg_enqueue_decode_tail(c, call);
+    if (rc) return rc;
+    c->last_stream = st;
+    c->pending = 2;
+    return KHG_OK;
+}
+
+// Waits for the last decode.  If the two speculative synchronisation passes did not agree
+// (a workgroup's 131072-bit span never resynchronised: e.g. fixed-length codes), more passes
+// are run here until every arrival is confirmed, then the tail is re-enqueued.
+static int khg_finish_decode(khg_ctx* c)
+{
+    KHG_HIP(hipEventSynchronize(c->done));
+    int status = c->h_res->status;
+    if (status != KHG_NOT_CONVERGED) return status;
+    KhgDecodeCall& call = c->dec_call;
+    hipStream_t st = call.st;
+    for (uint32_t pass = 2; pass < call.d.nblocks + 3; ++pass) {
+        KHG_HIP(hipMemsetAsync(c->ws.res, 0, sizeof(KhgResult), st));
+        KHG_HIP(hipMemsetAsync(call.d.mismatch, 0, sizeof(uint32_t), st));
+        khg_launch_sync_pass(call.d, (int)pass, st);
+        hipLaunchKernelGGL(khg_dec_scan_kernel, dim3(1), dim3(1024), 0, st, call.d);
+        KHG_HIP(hipMemcpyAsync(c->h_res, c->ws.res, sizeof(KhgResult), hipMemcpyDeviceToHost, st));
+        KHG_HIP(hipStreamSynchronize(st));
+        if (c->h_res->status != KHG_NOT_CONVERGED) break;
+    }
+    if (c->h_res->status != 0) return c->h_res->status == KHG_NOT_CONVERGED ? KHG_ERR_FORMAT : c->h_res->status;
+    int rc = khg_enqueue_decode_tail(c, call);
+    if (rc) return rc;
+    KHG_HIP(hipEventSynchronize(c->done));
+    return c->h_res->status;
+}
+
+extern "C" int khg_last_status(khg_ctx* c)
+{
+    if (!c) return KHG_ERR_ARG;
+    if (!c->pending) return KHG_OK;
+    int rc;
+    if (c->pending == 2) {
+        rc = khg_finish_decode(c);
+    } else {
+        KHG_HIP(hipEventSynchronize(c->done));
+        rc = c->h_res->status;
+    }
+    c->pending = 0;
+    return rc;
+}
+
+extern "C" int khg_decode(khg_ctx* c, const uint8_t* comp, size_t len, uint8_t* r, uint8_t* g, uint8_t* b)
+{
+    if (!c || !comp || !r || !g || !b) return KHG_ERR_ARG;
+    khg_header hd;
+    int rc = khg_peek(comp, len, &hd);
+    if (rc) return rc;
+    rc = khg_check_image(c, hd.h, hd.w);
+    if (rc) return rc;
+    KHG_HIP(hipSetDevice(c->device));
+    size_t n = (size_t)hd.h * hd.w;
+    size_t padded = (len + 3) & ~(size_t)3;
+    if ((rc = khg_stage(c, padded))) return rc;
+    KHG_HIP(hipMemcpy(c->stage_comp, comp, len, hipMemcpyHostToDevice));
+    uint8_t* d = c->stage_rgb;
+    rc = khg_decode_dev(c, c->stage_comp, len, hd.h, hd.w, d, d + n, d + 2 * n, nullptr);
+    if (rc) return rc;
+    rc = khg_last_status(c);
+    if (rc) return rc;
+    KHG_HIP(hipMemcpy(r, d, n, hipMemcpyDeviceToHost));
+    KHG_HIP(hipMemcpy(g, d + n, n, hipMemcpyDeviceToHost));
+    KHG_HIP(hipMemcpy(b, d + 2 * n, n, hipMemcpyDeviceToHost));
+    return KHG_OK;
+}
+
+// ------------------------------------------------------------------ metrics
+
+extern "C" int khg_ssim_dev(khg_ctx* c, const uint8_t* d_a, const uint8_t* d_b, int width, int height, double* ssim,
+                            void* stream)
+{
+    if (!c || !d_a || !d_b || !ssim) return KHG_ERR_ARG;
+    if (width < 8 || height < 8 || width > c->max_cols || height > c->max_rows) return KHG_ERR_DIMS;
+    hipStream_t st = (hipStream_t)stream;
+    KHG_HIP(hipSetDevice(c->device));
+    size_t nblk = (size_t)(width / 8) * (height / 8);
+    if (!c->h_ssim_blocks) {
+        size_t cap = ((size_t)c->max_rows / 8) * ((size_t)c->max_cols / 8);
+        KHG_HIP(hipHostMalloc((void**)&c->h_ssim_blocks, cap * sizeof(double)));
+    }
+    KhgSsimArgs a;
+    a.a = d_a; a.b = d_b; a.width = width; a.height = height; a.blocks = c->ssim_blocks;
+    hipLaunchKernelGGL(khg_ssim_kernel, dim3((unsigned)((nblk + 255) / 256)), dim3(256), 0, st, a);
+    KHG_HIP(hipGetLastError());
+    KHG_HIP(hipMemcpyAsync(c->h_ssim_blocks, c->ssim_blocks, nblk * sizeof(double), hipMemcpyDeviceToHost, st));
+    KHG_HIP(hipStreamSynchronize(st));
+    // SSIM.h:68-71: the mean is a sequential sum in raster order; done here so the result
+    // is bit-identical to the reference's (a parallel tree sum would differ in the last bits)
+    double sum = 0.0;
+    for (size_t i = 0; i < nblk; ++i) sum += c->h_ssim_blocks[i];
+    *ssim = sum / nblk;
+    return KHG_OK;
+}
+
+extern "C" int khg_psnr_dev(khg_ctx* c, const uint8_t* d_ir, const uint8_t* d_ig, const uint8_t* d_ib,
+                            const uint8_t* d_or, const uint8_t* d_og, const uint8_t* d_ob, int width, int height,
+                            double* psnr, void* stream)
+{
+    if (!c || !d_ir || !d_ig || !d_ib || !d_or || !d_og || !d_ob || !psnr) return KHG_ERR_ARG;
+    if (width <= 0 || height <= 0) return KHG_ERR_DIMS;
+    hipStream_t st = (hipStream_t)stream;
+    KHG_HIP(hipSetDevice(c->device));
+    KhgSseArgs a;
+    a.in[0] = d_ir; a.in[1] = d_ig; a.in[2] = d_ib;
+    a.out[0] = d_or; a.out[1] = d_og; a.out[2] = d_ob;
+    a.n = (size_t)width * height;
+    a.sse = c->sse;
+    KHG_HIP(hipMemsetAsync(c->sse, 0, 3 * sizeof(unsigned long long), st));
+    unsigned grid = (unsigned)((a.n + 255) / 256 < 2048 ? (a.n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(khg_sse_kernel, dim3(grid), dim3(256), 0, st, a);
+    KHG_HIP(hipGetLastError());
+    unsigned long long h[3];
+    KHG_HIP(hipMemcpyAsync(h, c->sse, sizeof h, hipMemcpyDeviceToHost, st));
+    KHG_HIP(hipStreamSynchronize(st));
+    // KhuGleBase.cpp:609-626
+    double MseR = (double)h[0], MseG = (double)h[1], MseB = (double)h[2];
+    MseR /= width * height;
+    MseG /= width * height;
+    MseB /= width * height;
+    double Mse = (MseR + MseG + MseB) / 3.;
+    *psnr = Mse == 0 ? 100. : 10 * log10(255 * 255 / Mse);
+    return KHG_OK;
+}

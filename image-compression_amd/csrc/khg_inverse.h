@@ -1,0 +1,198 @@
+// khg_inverse.h -- dequantiser + one inverse 2-D CDF 9/7 lifting level, and the final
+// YCbCr -> RGB conversion.
+//
+// Mirror image of khg_forward.h (IWT2D runs columns first, then rows: DWT.h:143-165).
+// One workgroup walks down a strip of 240 output columns.  Per batch of 8 row pairs:
+//   columns: 248 threads each own one packed source column (124 low + 124 high, i.e. the
+//            strip's 120 + 120 plus a 2-pair halo each side); a thread reads its low/high
+//            coefficient pair (symbols are dequantised on the fly, Decompress.h:98-123),
+//            feeds the streaming inverse lifting pipeline in registers, and stores the two
+//            finished natural-order rows in LDS tile T
+//   rows   : each thread inverse-lifts a run of 16 outputs of one row from 12 low + 12 high
+//            values of T and writes them to the destination plane.
+#pragma once
+#include "khg_common.h"
+#include "khg_decode.h"
+
+enum {
+    KHG_ISTRIP = 240,
+    KHG_IHALF = KHG_ISTRIP / 2 + 4,   // 124 packed columns per half (2-pair halo each side)
+    KHG_ICOLS = 2 * KHG_IHALF,        // 248 column threads
+    KHG_T_PITCH = KHG_ICOLS + 1,
+    KHG_IBATCH = 8                    // row pairs per batch
+};
+
+struct KhgInvArgs {
+    const int16_t* sym;   // symbol plane of this colour component
+    int sym_pitch;
+    const double* ll;     // level 1: the LL quadrant (output of the level-2 inverse)
+    int ll_pitch;
+    int ph, pw;           // rows, cols of this transform
+    double* dst;          // natural-order output, ph x pw
+    int dst_pitch;
+    const KhgDecHeader* hdr;  // supplies the preset (lvl) and the go/no-go flag
+    int seg_rows;         // output rows per workgroup segment (even)
+    int nstrip;
+    KhgQuant q[3];        // quantiser constants of this plane type for presets 0..2
+};
+
+struct KhgInvSmem {
+    double T[2 * KHG_IBATCH * KHG_T_PITCH];
+};
+
+// State after feeding pair j: d_in[j], s1[j], d1[j-1], s0[j-1].
+struct KhgILift {
+    double d, s1, d1, s0;
+};
+
+// Feed packed pair j = (low[j], high[j]); returns natural samples x[2(j-2)], x[2(j-2)+1].
+// With s[k] = low[k]/A, d[k] = high[k]*A (DWT.h:76-82, A = 1.149604398) the steps of DWT.h:84-114 read
+//   s1[k] = s[k]  + C1*(d[k-1]  + d[k])        undo update 2
+//   d1[k] = d[k]  + C2*(s1[k]   + s1[k+1])     undo predict 2
+//   s0[k] = s1[k] + C3*(d1[k-1] + d1[k])       undo update 1
+//   d0[k] = d1[k] + C4*(s0[k]   + s0[k+1])     undo predict 1
+KHG_DEV void khg_inv_step(KhgILift& st, double lo, double hi, double& xe, double& xo)
+{
+    const double A = 1.149604398;
+    const double C1 = -0.4435068522, C2 = -0.8829110762, C3 = 0.05298011854, C4 = 1.586134342;
+    double sn = lo / A, dn = hi * A;
+    double s1n = sn + C1 * (st.d + dn);
+    double d1n = st.d + C2 * (st.s1 + s1n);
+    double s0n = st.s1 + C3 * (st.d1 + d1n);
+    double d0 = st.d1 + C4 * (st.s0 + s0n);
+    xe = st.s0;
+    xo = d0;
+    st.d = dn;
+    st.s1 = s1n;
+    st.d1 = d1n;
+    st.s0 = s0n;
+}
+
+// Coefficient at packed position (yo, xo) of the plane being inverted.
+template <int LEVEL>
+KHG_DEV double khg_inv_load(const KhgInvArgs& a, const KhgQuant& qc, int lvl, int yo, int xo, int hh, int hw)
+{
+    int band;
+    if (LEVEL == 2) {
+        band = (yo >= hh ? 2 : 0) + (xo >= hw ? 1 : 0);
+    } else {
+        if (yo < hh && xo < hw) return a.ll[(size_t)yo * a.ll_pitch + xo];
+        band = yo < hh ? 4 : (xo < hw ? 5 : 6);
+    }
+    int q = a.sym[(size_t)yo * a.sym_pitch + xo];
+    return (double)q * khg_divisor(qc, band, xo, yo, lvl);  // Decompress.h:105, 120-121
+}
+
+template <int LEVEL>
+KHG_DEV void khg_inv_strip_body(const KhgInvArgs& a, int bid, KhgInvSmem& sh)
+{
+    const int strip = bid % a.nstrip, seg = bid / a.nstrip;
+    const int x0 = strip * KHG_ISTRIP;
+    const int r0 = seg * a.seg_rows;
+    const int r1 = (r0 + a.seg_rows < a.ph) ? r0 + a.seg_rows : a.ph;
+    const int k0 = r0 / 2, k1 = r1 / 2;
+    const int nb = (k1 - k0 + 4 + KHG_IBATCH - 1) / KHG_IBATCH;
+    const int hh = a.ph / 2, hw = a.pw / 2;
+    if (!a.hdr->ok) return;
+    const int lvl = a.hdr->lvl;
+    const KhgQuant& qc = a.q[lvl];
+
+    KhgILift cs[KHG_NSLOT(256)];
+    KHG_FOR_THREADS(256)
+    {
+        KhgILift z = {0, 0, 0, 0};
+        cs[KHG_SLOT] = z;
+    }
+    for (int b = 0; b < nb; ++b) {
+        KHG_FOR_THREADS(256)
+        {
+            if (tid < KHG_ICOLS) {
+                // ---- column phase: packed source column of this thread
+                const int half = tid >= KHG_IHALF, tt = half ? tid - KHG_IHALF : tid;
+                const int rx = khg_reflect(2 * ((x0 >> 1) - 2 + tt) + half, a.pw);  // natural column, parity = half
+                const int xo = (rx >> 1) + (half ? hw : 0);
+                KhgILift st = cs[KHG_SLOT];
+                for (int s = 0; s < KHG_IBATCH; ++s) {
+                    int j = k0 - 2 + b * KHG_IBATCH + s;  // row pair fed in this step
+                    int ye = khg_reflect(2 * j, a.ph) >> 1;
+                    int yo = hh + (khg_reflect(2 * j + 1, a.ph) >> 1);
+                    double lo = khg_inv_load<LEVEL>(a, qc, lvl, ye, xo, hh, hw);
+                    double hi = khg_inv_load<LEVEL>(a, qc, lvl, yo, xo, hh, hw);
+                    double xe, xod;
+                    khg_inv_step(st, lo, hi, xe, xod);
+                    sh.T[(2 * s) * KHG_T_PITCH + tid] = xe;
+                    sh.T[(2 * s + 1) * KHG_T_PITCH + tid] = xod;
+                }
+                cs[KHG_SLOT] = st;
+            }
+        }
+        KHG_BARRIER();
+        KHG_FOR_THREADS(256)
+        {
+            // ---- row phase: natural row of T, outputs [16*run, 16*run+16) of the strip
+            const int rr = tid & 15, run = tid >> 4;
+            const int pair = k0 - 4 + b * KHG_IBATCH + (rr >> 1);  // column phase step s emitted pair j-2
+            const int gy = 2 * pair + (rr & 1);
+            const int gx0 = x0 + run * 16;
+            if (run < KHG_ISTRIP / 16 && pair >= k0 && pair < k1 && gx0 < a.pw) {
+                const double* lo = &sh.T[rr * KHG_T_PITCH + run * 8];
+                const double* hi = lo + KHG_IHALF;
+                double* out = a.dst + (size_t)gy * a.dst_pitch + gx0;
+                KhgILift st = {0, 0, 0, 0};
+                KHG_UNROLL
+                for (int i = 0; i < 12; ++i) {
+                    double xe, xod;
+                    khg_inv_step(st, lo[i], hi[i], xe, xod);
+                    if (i >= 4 && gx0 + 2 * (i - 4) < a.pw) {  // pw is even: a pair never straddles the edge
+                        out[2 * (i - 4)] = xe;
+                        out[2 * (i - 4) + 1] = xod;
+                    }
+                }
+            }
+        }
+        KHG_BARRIER();
+    }
+}
+
+// Colorspace.h:25-36 + Main.cpp:307-315: 4 pixels per thread.
+struct KhgRgbArgs {
+    const double *y, *cb, *cr;
+    uint8_t *r, *g, *b;
+    int rows, cols;
+};
+
+KHG_DEV uint8_t khg_clamp_u8(double v)
+{
+    // max(0, min(v, 255)) with the Win32 macros (a<b?a:b), (a>b?a:b), then truncation to unsigned char
+    double m = (v < 255.0) ? v : 255.0;
+    double c = (0.0 > m) ? 0.0 : m;
+    return (uint8_t)c;
+}
+
+KHG_DEV void khg_rgb_body(const KhgRgbArgs& a, uint32_t bid, uint32_t nblk)
+{
+    const size_t quads = (size_t)a.rows * a.cols / 4;
+    const int cw = a.cols / 2;
+    KHG_FOR_THREADS(256)
+    {
+        for (size_t qd = (size_t)bid * 256 + tid; qd < quads; qd += (size_t)nblk * 256) {
+            size_t p = qd * 4;
+            int yy = (int)(p / (size_t)a.cols), xx = (int)(p - (size_t)yy * a.cols);
+            uint32_t pr = 0, pg = 0, pb = 0;
+            for (int i = 0; i < 4; ++i) {
+                double Y = a.y[p + i];
+                size_t c = (size_t)(yy / 2) * cw + (xx + i) / 2;
+                double Cb = a.cb[c], Cr = a.cr[c];
+                double R = Y * 1 + Cr * 1.402;
+                double G = Y * 1 + Cb * -0.34414 + Cr * -0.71414;
+                double B = Y * 1 + Cb * 1.772;
+                pr |= (uint32_t)khg_clamp_u8(R) << (8 * i);
+                pg |= (uint32_t)khg_clamp_u8(G) << (8 * i);
+                pb |= (uint32_t)khg_clamp_u8(B) << (8 * i);
+            }
+            *(uint32_t*)(a.r + p) = pr;
+            *(uint32_t*)(a.g + p) = pg;
+            *(uint32_t*)(a.b + p) = pb;
+        }
+    }
+}

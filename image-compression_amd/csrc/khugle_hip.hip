@@ -11,11 +11,7 @@
 #include "khugle_hip.h"
 #include "khg_plan.h"
 #include "khg_synth.h"
-#ifdef KHG_WITH_DECODE
-#include "khg_decode.h"
-#include "khg_inverse.h"
-#include "khg_metrics.h"
-#endif
+#include "khg_dec_plan.h"
 
 // ------------------------------------------------------------------ kernels
 
@@ -60,7 +56,6 @@ __global__ __launch_bounds__(256) void khg_synth_kernel(uint8_t* r, uint8_t* g, 
     }
 }
 
-#ifdef KHG_WITH_DECODE
 __global__ __launch_bounds__(256) void khg_dec_header_kernel(KhgDecArgs a)
 {
     khg_dec_header_body(a);
@@ -90,11 +85,11 @@ __global__ __launch_bounds__(256) void khg_dec_write_kernel(KhgDecArgs a)
     khg_dec_write_body(a, blockIdx.x, sh);
 }
 
-template <int LEVEL, int DST>
+template <int LEVEL>
 __global__ __launch_bounds__(256) void khg_inv_kernel(KhgInvArgs a)
 {
     __shared__ KhgInvSmem sh;
-    khg_inv_strip_body<LEVEL, DST>(a, (int)blockIdx.x, sh);
+    khg_inv_strip_body<LEVEL>(a, (int)blockIdx.x, sh);
 }
 
 __global__ __launch_bounds__(256) void khg_ssim_kernel(KhgSsimArgs a)
@@ -108,7 +103,6 @@ __global__ __launch_bounds__(256) void khg_sse_kernel(KhgSseArgs a)
     khg_sse_body(a, blockIdx.x, gridDim.x, sh);
 }
 
-#endif  // KHG_WITH_DECODE
 
 // ------------------------------------------------------------------ context
 
@@ -121,13 +115,19 @@ __global__ __launch_bounds__(256) void khg_sse_kernel(KhgSseArgs a)
         }                                                                                               \
     } while (0)
 
+struct KhgDecodeCall {
+    KhgDecArgs d;
+    uint8_t *r, *g, *b;
+    int rows, cols;
+    hipStream_t st;
+};
+
 struct khg_ctx {
     int device;
     int max_rows, max_cols;
     KhgWorkspace ws;
-#ifdef KHG_WITH_DECODE
     KhgDecWorkspace dws;
-#endif
+    KhgDecodeCall dec_call;  // arguments of the last decode (for the rare extra sync passes)
     void* slab;          // one device allocation carved into the workspace
     size_t slab_bytes;
     KhgResult* h_res;    // pinned host copy of ws.res
@@ -182,10 +182,8 @@ extern "C" int khg_ctx_create(int device, int max_rows, int max_cols, khg_ctx** 
 
     KhgWorkspaceSizes s;
     khg_workspace_sizes(max_rows, max_cols, &s);
-#ifdef KHG_WITH_DECODE
     KhgDecWorkspaceSizes ds;
     khg_dec_workspace_sizes(max_rows, max_cols, &ds);
-#endif
     size_t nblk = ((size_t)max_rows / 8) * ((size_t)max_cols / 8);
     size_t total = 0;
     auto take = [&](size_t bytes) { size_t o = total; total += khg_align(bytes); return o; };
@@ -194,11 +192,9 @@ extern "C" int khg_ctx_create(int device, int max_rows, int max_cols, khg_ctx** 
     size_t o_hc = take(s.hist), o_hf = take(s.hist), o_tc = take(s.tab), o_ts = take(s.tab), o_tk = take(64);
     size_t o_ct = take(s.codetab), o_bs = take(s.big_scratch), o_tl = take(s.tree), o_tr = take(s.tree), o_troot = take(64);
     size_t o_cb = take(s.chunk_bits), o_co = take(s.chunk_off), o_res = take(sizeof(KhgResult));
-#ifdef KHG_WITH_DECODE
     size_t o_plane[3];
     for (int p = 0; p < 3; ++p) o_plane[p] = take(ds.plane[p]);
     size_t o_lut = take(ds.lut), o_sub = take(ds.sub), o_hdr = take(sizeof(KhgDecHeader));
-#endif
     size_t o_ssim = take(nblk * sizeof(double)), o_sse = take(64);
     c->slab_bytes = total;
     if (hipMalloc(&c->slab, total) != hipSuccess) { delete c; return KHG_ERR_NOMEM; }
@@ -210,12 +206,10 @@ extern "C" int khg_ctx_create(int device, int max_rows, int max_cols, khg_ctx** 
     c->ws.tree_left = (int32_t*)(base + o_tl); c->ws.tree_right = (int32_t*)(base + o_tr); c->ws.tree_root = (int32_t*)(base + o_troot);
     c->ws.chunk_bits = (uint32_t*)(base + o_cb); c->ws.chunk_off = (uint64_t*)(base + o_co);
     c->ws.res = (KhgResult*)(base + o_res);
-#ifdef KHG_WITH_DECODE
     for (int p = 0; p < 3; ++p) c->dws.plane[p] = (double*)(base + o_plane[p]);
     c->dws.lut = (uint32_t*)(base + o_lut);
     c->dws.sub = (KhgSubInfo*)(base + o_sub);
     c->dws.hdr = (KhgDecHeader*)(base + o_hdr);
-#endif
     c->ssim_blocks = (double*)(base + o_ssim);
     c->sse = (unsigned long long*)(base + o_sse);
     if (hipMemset(c->slab, 0, total) != hipSuccess || hipHostMalloc((void**)&c->h_res, sizeof(KhgResult)) != hipSuccess ||
@@ -309,17 +303,10 @@ extern "C" int khg_encode_dev(khg_ctx* c, const uint8_t* d_r, const uint8_t* d_g
 extern "C" int khg_encode_result(khg_ctx* c, size_t* out_len)
 {
     if (!c) return KHG_ERR_ARG;
-    if (!c->pending) return KHG_ERR_ARG;
+    if (c->pending != 1) return KHG_ERR_ARG;
     KHG_HIP(hipEventSynchronize(c->done));
+    c->pending = 0;
     if (out_len) *out_len = (size_t)c->h_res->total_len;
-    return c->h_res->status;
-}
-
-extern "C" int khg_last_status(khg_ctx* c)
-{
-    if (!c) return KHG_ERR_ARG;
-    if (!c->pending) return KHG_OK;
-    KHG_HIP(hipEventSynchronize(c->done));
     return c->h_res->status;
 }
 
@@ -412,6 +399,4 @@ extern "C" int khg_synth_dev(uint8_t* d_r, uint8_t* d_g, uint8_t* d_b, int rows,
     return KHG_OK;
 }
 
-#ifdef KHG_WITH_DECODE
 #include "khg_host_decode.inl"
-#endif

@@ -64,8 +64,6 @@ def load():
                               "there is no CPU fallback" % (LIB_PATH, CSRC))
         lib = C.CDLL(LIB_PATH)
         for name, res, args in SYMBOLS:
-            if os.environ.get("KHG_PARTIAL") and not hasattr(lib, name):
-                continue
             fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
             fn.restype = res
             fn.argtypes = args

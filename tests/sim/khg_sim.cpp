@@ -11,6 +11,7 @@
 
 #define KHG_SIM 1
 #include "khg_plan.h"
+#include "khg_dec_plan.h"
 #include "khg_synth.h"
 
 namespace {
@@ -32,7 +33,14 @@ struct SimWs {
         ws.tree_left = alloc<int32_t>(s.tree); ws.tree_right = alloc<int32_t>(s.tree); ws.tree_root = alloc<int32_t>(16);
         ws.chunk_bits = alloc<uint32_t>(s.chunk_bits); ws.chunk_off = alloc<uint64_t>(s.chunk_off);
         ws.res = alloc<KhgResult>(sizeof(KhgResult));
+        KhgDecWorkspaceSizes d;
+        khg_dec_workspace_sizes(rows, cols, &d);
+        for (int p = 0; p < 3; ++p) dws.plane[p] = alloc<double>(d.plane[p]);
+        dws.lut = alloc<uint32_t>(d.lut);
+        dws.sub = alloc<KhgSubInfo>(d.sub);
+        dws.hdr = alloc<KhgDecHeader>(sizeof(KhgDecHeader));
     }
+    KhgDecWorkspace dws;
 };
 
 template <int SRC, int LEVEL>
@@ -96,6 +104,84 @@ int khgsim_encode(const uint8_t* r, const uint8_t* g, const uint8_t* b, int rows
     delete psh;
     if (out_len) *out_len = (size_t)S.ws.res->total_len;
     return S.ws.res->status;
+}
+
+// Mirrors khg_decode_dev + khg_finish_decode.  max_passes = 0 means "as many as needed".
+int khgsim_decode(const uint8_t* comp, size_t len, int rows, int cols, uint8_t* r, uint8_t* g, uint8_t* b,
+                  int16_t* qy, int16_t* qcb, int16_t* qcr, int* passes_used) {
+    if (!khg_dims_ok(rows, cols)) return -1;
+    SimWs S(rows, cols);
+    std::vector<uint8_t> buf((len + 3) & ~(size_t)3, 0);
+    memcpy(buf.data(), comp, len);
+    KhgDecArgs d = khg_dec_args(S.ws, S.dws, buf.data(), len, rows, cols);
+    memset(S.ws.res, 0, sizeof(KhgResult));
+    khg_dec_header_body(d);
+    KhgDecTreeSmem* tsh = new KhgDecTreeSmem;
+    for (int p = 0; p < 3; ++p) khg_dec_tree_body(d, p, *tsh);
+    delete tsh;
+    KhgDecLut* lsh = new KhgDecLut;
+    KhgDecScanSmem* ssh = new KhgDecScanSmem;
+    int pass = 0;
+    for (;; ++pass) {
+        if (pass >= 2) { S.ws.res->status = 0; d.mismatch[0] = 0; }
+        d.pass = pass;
+        for (uint32_t b_ = 0; b_ < d.nblocks; ++b_) khg_dec_sync_body(d, b_, *lsh);
+        if (pass == 0) continue;
+        khg_dec_scan_body(d, *ssh);
+        if (S.ws.res->status != KHG_NOT_CONVERGED || pass > (int)d.nblocks + 3) break;
+    }
+    if (passes_used) *passes_used = pass + 1;
+    for (uint32_t b_ = 0; b_ < d.nblocks; ++b_) khg_dec_write_body(d, b_, *lsh);
+    delete lsh;
+    delete ssh;
+    KhgInvSmem* ish = new KhgInvSmem;
+    KhgFwdGrid gr;
+    for (int p = 0; p < 3; ++p) {
+        KhgInvArgs a = khg_inv_args(S.ws, S.dws, rows, cols, p, 2, &gr);
+        for (int bid = 0; bid < gr.nstrip * gr.nseg; ++bid) khg_inv_strip_body<2>(a, bid, *ish);
+    }
+    for (int p = 0; p < 3; ++p) {
+        KhgInvArgs a = khg_inv_args(S.ws, S.dws, rows, cols, p, 1, &gr);
+        for (int bid = 0; bid < gr.nstrip * gr.nseg; ++bid) khg_inv_strip_body<1>(a, bid, *ish);
+    }
+    delete ish;
+    KhgRgbArgs ra;
+    ra.y = S.dws.plane[0]; ra.cb = S.dws.plane[1]; ra.cr = S.dws.plane[2];
+    ra.r = r; ra.g = g; ra.b = b; ra.rows = rows; ra.cols = cols;
+    for (uint32_t bid = 0; bid < 4; ++bid) khg_rgb_body(ra, bid, 4);
+    size_t ny = (size_t)rows * cols;
+    if (qy) memcpy(qy, S.ws.sym[0], ny * 2);
+    if (qcb) memcpy(qcb, S.ws.sym[1], ny / 4 * 2);
+    if (qcr) memcpy(qcr, S.ws.sym[2], ny / 4 * 2);
+    return S.ws.res->status;
+}
+
+double khgsim_ssim(const uint8_t* a, const uint8_t* b, int width, int height, double* blocks_out) {
+    size_t nblk = (size_t)(width / 8) * (height / 8);
+    std::vector<double> blocks(nblk);
+    KhgSsimArgs s;
+    s.a = a; s.b = b; s.width = width; s.height = height; s.blocks = blocks.data();
+    for (uint32_t bid = 0; bid < (nblk + 255) / 256; ++bid) khg_ssim_body(s, bid);
+    double sum = 0.0;
+    for (size_t i = 0; i < nblk; ++i) sum += blocks[i];
+    if (blocks_out) memcpy(blocks_out, blocks.data(), nblk * sizeof(double));
+    return sum / nblk;
+}
+
+void khgsim_sse(const uint8_t* const in[3], const uint8_t* const out[3], size_t n, unsigned long long sse[3]) {
+    KhgSseArgs a;
+    for (int c = 0; c < 3; ++c) { a.in[c] = in[c]; a.out[c] = out[c]; sse[c] = 0; }
+    a.n = n; a.sse = sse;
+    KhgSseSmem sh;
+    for (uint32_t bid = 0; bid < 3; ++bid) khg_sse_body(a, bid, 3, sh);
+}
+
+void khgsim_synth(uint8_t* r, uint8_t* g, uint8_t* b, int rows, int cols, uint32_t seed, uint32_t index) {
+    for (int y = 0; y < rows; ++y)
+        for (int x = 0; x < cols; ++x) {
+            size_t i = (size_t)y * cols + x;
+            khg_synth_pixel((uint32_t)y, (uint32_t)x, (uint32_t)cols, seed, index, &r[i], &g[i], &b[i]);
+        }
 }
 
 }  // extern "C"

@@ -1,0 +1,106 @@
+"""GPU parity of the decode path and the quality metrics against the CPU oracle (bit-exact pixels)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, IMAGES, RUN
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.parametrize("ref", ["cat_high", "couple_normal", "library_extreme"])
+def test_decode_reference_comp_files(codec, ref):
+    """Decode-only of the .comp files the reference ships: pixels equal the oracle's, bit for bit."""
+    import oracle_py as O
+    comp = open(os.path.join(RUN, ref + ".comp"), "rb").read()
+    assert np.array_equal(codec.decode(comp), O.decode(comp))
+
+
+@pytest.mark.parametrize("name", IMAGES)
+@pytest.mark.parametrize("lvl", [0, 1, 2])
+def test_roundtrip_run_images(codec, run_images, name, lvl):
+    import oracle_py as O
+    rgb = run_images[name]
+    comp = codec.encode(rgb, lvl)
+    got = codec.decode(comp)
+    assert np.array_equal(got, O.decode(comp))
+
+
+def test_published_quality_figures(codec, run_images):
+    """cat.bmp reproduces the PSNR / SSIM / size strings of the reference's screenshots."""
+    shots = json.load(open(os.path.join(GOLDEN, "screenshots.json")))
+    rgb = run_images["cat"]
+    d_in = _dev(rgb)
+    for lvl, want in shots["presets"].items():
+        comp = codec.encode(rgb, int(lvl))
+        d_out = _dev(codec.decode(comp))
+        psnr = codec.psnr_dev(d_in, d_out)
+        ssim = codec.ssim_dev(d_in[0], d_out[0])
+        assert "%6.3f" % psnr == want["psnr"]
+        assert "%4.3f" % ssim == want["ssim"]
+        assert "%6.3f" % (len(comp) / 1024) == want["size_kb"]
+        assert "%.3f" % (len(comp) / shots["bmp_bytes"] * 100) == want["percent"]
+
+
+@pytest.mark.parametrize("shape", [(8, 8), (16, 24), (64, 64), (264, 520), (512, 256), (1024, 1024), (1080, 1920)])
+@pytest.mark.parametrize("lvl", [0, 1, 2])
+def test_synthetic_decode_and_metrics(codec, shape, lvl):
+    import oracle_py as O
+    from khugle_amd import synth_frame
+    rgb = synth_frame(shape[0], shape[1], 11, lvl)
+    comp = O.encode(rgb, lvl)
+    got = codec.decode(comp)
+    want = O.decode(comp)
+    assert np.array_equal(got, want)
+    d_in, d_out = _dev(rgb), _dev(got)
+    assert codec.psnr_dev(d_in, d_out) == O.psnr(rgb, want)      # exact
+    assert codec.ssim_dev(d_in[0], d_out[0]) == O.ssim(rgb[0], want[0])  # exact (raster-order sum)
+
+
+def test_decode_dev_async(codec):
+    import torch
+    import oracle_py as O
+    from khugle_amd import synth_frame
+    rgb = synth_frame(512, 768, 5, 2)
+    d = _dev(rgb)
+    out = torch.zeros(codec.comp_bound(512, 768), dtype=torch.uint8, device="cuda")
+    dec = torch.zeros((3, 512, 768), dtype=torch.uint8, device="cuda")
+    codec.encode_dev(d, 1, out)
+    n = codec.encode_result()
+    codec.decode_dev(out, n, 512, 768, dec)
+    assert codec.last_status() == 0
+    assert np.array_equal(dec.cpu().numpy(), O.decode(out[:n].cpu().numpy().tobytes()))
+
+
+def test_fixed_length_codes_need_extra_sync_passes(codec):
+    """Four equiprobable symbols give 2-bit codes that never self-synchronise from an odd
+    offset: the speculative two-pass decode must detect it and still return exact pixels."""
+    import oracle_py as O
+    rng = np.random.default_rng(3)
+    rgb = rng.integers(0, 256, (3, 1024, 1024), dtype=np.uint8)
+    comp = O.encode(rgb, 2)
+    assert np.array_equal(codec.decode(comp), O.decode(comp))
+
+
+def test_malformed_files_are_rejected(codec):
+    import oracle_py as O
+    from khugle_amd import synth_frame, KhgError
+    comp = bytearray(O.encode(synth_frame(64, 64, 1, 0), 1))
+    bad = bytes(comp[:100])
+    with pytest.raises(KhgError):
+        codec.decode(bad)
+    c2 = bytearray(comp)
+    c2[32] = 9  # pad > 7
+    with pytest.raises(KhgError):
+        codec.decode(bytes(c2))
+    c3 = bytearray(comp)
+    c3[35] = 7  # preset out of range
+    with pytest.raises(KhgError):
+        codec.decode(bytes(c3))
