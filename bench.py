@@ -1,0 +1,248 @@
+#!/usr/bin/env python3
+"""bench.py -- encode+decode throughput of the KhuGle codec path on MI355X.
+
+Workload (BASELINE.json config "Synthetic 7680x4320 RGB batch of 1024 frames, High preset,
+batch-sharded over 1/2/4/8 GPUs"): every rank owns 128 distinct synthetic 8K frames (1024 / 8),
+already resident in HBM.  One step = encode all of them to .comp bytes, then decode all of them
+back to RGB (device to device).  Frames are independent, so ranks exchange nothing on the data
+path (weak scaling); torch.distributed (RCCL) only provides the barrier and the max-over-ranks.
+
+Prints ONE JSON line on rank 0.  `value` = megapixels that went through encode AND decode per
+second, whole job.  `roofline` prices the longest kernel (level-1 luma forward transform) against
+the 8 TB/s HBM peak with HIP-event timing taken live; `cpu_baseline` times the reference's own
+DWT / Huffman / file code (oracle/_ref, built from the reference's headers) on the host cores
+on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (os.path.join(ROOT, "image-compression_amd", "python"), os.path.join(ROOT, "oracle")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+ROWS, COLS, LVL, SEED = 4320, 7680, 1, 2025
+HBM_PEAK_GBS = 8000.0
+# level-1 luma forward kernel, algorithmic bytes per luma pixel: 3 (u8 R,G,B read)
+# + 2 (LL quadrant written as f64: 8 B on a quarter of the samples)
+# + 1.5 (int16 symbols of the three detail sub-bands: 2 B on three quarters)
+LUMA_FWD_BYTES_PER_PX = 6.5
+
+
+def _cpu_worker(args):
+    """One host process: encode+decode `frames` square frames with the reference's own code."""
+    side, seed, first, frames, lvl = args
+    import ctypes as C
+    import tempfile
+    import numpy as np
+    import oracle_py as O
+    from khugle_amd.synth import synth_frame
+    R = O.ref()
+    path = os.path.join(tempfile.gettempdir(), "khg_cpu_%d.comp" % os.getpid()).encode()
+    imgs = [synth_frame(side, side, seed, first + i) for i in range(frames)]
+    t0 = time.perf_counter()
+    te = td = 0.0
+    for rgb in imgs:
+        a = time.perf_counter()
+        if R is not None:
+            R.kref_encode_file(rgb[0], rgb[1], rgb[2], side, lvl, path)
+        else:
+            comp = O.encode(rgb, lvl, faithful=True)
+        b = time.perf_counter()
+        if R is not None:
+            out = np.zeros_like(rgb)
+            n = C.c_int(0)
+            R.kref_decode_file(path, out[0], out[1], out[2], C.byref(n))
+        else:
+            O.decode(comp)
+        c = time.perf_counter()
+        te += b - a
+        td += c - b
+    try:
+        os.unlink(path.decode())
+    except OSError:
+        pass
+    return time.perf_counter() - t0, te, td
+
+
+def cpu_baseline(side=2048, frames_per_core=1):
+    import multiprocessing as mp
+    import oracle_py as O
+    cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+    cores = max(1, min(cores, 16))
+    O.build()
+    kind = "reference" if O.have_ref() else "port"
+    jobs = [(side, SEED, i * frames_per_core, frames_per_core, LVL) for i in range(cores)]
+    t0 = time.perf_counter()
+    with mp.get_context("spawn").Pool(cores) as pool:
+        res = pool.map(_cpu_worker, jobs)
+    wall = time.perf_counter() - t0
+    busy = max(r[0] for r in res)
+    mp_total = cores * frames_per_core * side * side / 1e6
+    per_core_enc = side * side / 1e6 / (sum(r[1] for r in res) / (cores * frames_per_core))
+    per_core_dec = side * side / 1e6 / (sum(r[2] for r in res) / (cores * frames_per_core))
+    what = ("reference DWT.h/Huffman.h/Writer.h/Reader.h compiled as they are + restated colour/quantiser"
+            if kind == "reference" else "CPU restatement with the reference's O(N*K) table search")
+    return {"value": round(mp_total / busy, 3), "unit": "MP/s encode+decode", "cores": cores, "kind": kind,
+            "sample": "%d frames of %dx%d (same generator, seed %d, High preset; the reference cannot "
+                      "round-trip non-square frames), one process per core, %s; per core: encode %.2f MP/s, "
+                      "decode %.2f MP/s; pool wall %.1f s" % (cores * frames_per_core, side, side, SEED, what,
+                                                               per_core_enc, per_core_dec, wall)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--frames", type=int, default=128, help="frames per GPU per step")
+    ap.add_argument("--streams", type=int, default=4, help="contexts/streams in flight per GPU")
+    ap.add_argument("--rows", type=int, default=ROWS)
+    ap.add_argument("--cols", type=int, default=COLS)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import khugle_amd
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (the codec has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    rows, cols, F, S = args.rows, args.cols, args.frames, max(1, min(args.streams, args.frames))
+    px = rows * cols
+    ctxs = [khugle_amd.Codec(rows, cols, device=local_rank) for _ in range(S)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
+    # inputs resident in HBM before the timed region: frames rank*F .. rank*F+F-1 of the synthetic batch
+    frames = torch.empty((F, 3, rows, cols), dtype=torch.uint8, device=dev)
+    for f in range(F):
+        ctxs[0].synth_dev(rows, cols, SEED, rank * F + f, out=frames[f])
+    cap = (2 * px + (1 << 20)) & ~3  # 2 bytes per pixel: ~7x the High-preset size, checked by the encoder
+    comps = torch.zeros((F, cap), dtype=torch.uint8, device=dev)
+    decs = torch.empty((S, 3, rows, cols), dtype=torch.uint8, device=dev)
+    lens = [0] * F
+    torch.cuda.synchronize()
+
+    def encode_pass():
+        for f in range(F):
+            c = f % S
+            if f >= S:
+                lens[f - S] = ctxs[c].encode_result()
+            with torch.cuda.stream(streams[c]):
+                ctxs[c].encode_dev(frames[f], LVL, comps[f])
+        for f in range(max(0, F - S), F):
+            lens[f] = ctxs[f % S].encode_result()
+
+    def decode_pass():
+        for f in range(F):
+            c = f % S
+            if f >= S and ctxs[c].last_status() != 0:
+                raise RuntimeError("decode failed")
+            with torch.cuda.stream(streams[c]):
+                ctxs[c].decode_dev(comps[f], lens[f], rows, cols, decs[c])
+        for c in range(S):
+            if ctxs[c].last_status() != 0:
+                raise RuntimeError("decode failed")
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        encode_pass()
+        decode_pass()
+    barrier()
+    t_enc = t_dec = 0.0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        a = time.perf_counter()
+        encode_pass()
+        torch.cuda.synchronize()
+        b = time.perf_counter()
+        decode_pass()
+        torch.cuda.synchronize()
+        c = time.perf_counter()
+        t_enc += b - a
+        t_dec += c - b
+    barrier()
+    elapsed = time.perf_counter() - t0
+    tt = torch.tensor([elapsed, t_enc, t_dec], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    elapsed, t_enc, t_dec = [float(x) for x in tt.cpu()]
+
+    # dominant kernel, timed live with HIP events on the stream it is launched on
+    with torch.cuda.stream(streams[0]):
+        k_ms = ctxs[0].time_luma_forward_dev(frames[0], LVL, reps=20)
+    achieved = LUMA_FWD_BYTES_PER_PX * px / (k_ms * 1e-3) / 1e9
+
+    if rank == 0:
+        # parity spot check (untimed): the last frame's bytes and pixels against the CPU oracle
+        parity = None
+        try:
+            import oracle_py as O
+            f = F - 1
+            rgb = frames[f].cpu().numpy()
+            comp = comps[f, :lens[f]].cpu().numpy().tobytes()
+            want = O.encode(rgb, LVL)
+            dec = decs[f % S].cpu().numpy()
+            parity = bool(comp == want) and bool(np.array_equal(dec, O.decode(want)))
+        except Exception as e:  # the oracle is test infrastructure: never let it break the measurement
+            parity = "unavailable: %s" % e
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "luma_forward_traffic.json")
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline()
+        total_mp = world * F * args.steps * px / 1e6
+        bpp = 8.0 * sum(lens) / (F * px)
+        line = {
+            "metric": "encode+decode megapixels/sec (node), 8K batch, High preset",
+            "value": round(total_mp / elapsed, 1),
+            "unit": "MP/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "synthetic %dx%d RGB, %d frames per GPU per step (1024-frame batch sharded "
+                                   "over 8 GPUs), High preset, encode to .comp then decode to RGB, device resident"
+                                   % (cols, rows, F),
+                       "frames_per_gpu": F, "streams_per_gpu": S, "seed": SEED, "bits_per_pixel": round(bpp, 4)},
+            "encode_mp_s": round(total_mp / t_enc, 1),
+            "decode_mp_s": round(total_mp / t_dec, 1),
+            "parity_spot_check": parity,
+            "roofline": {"bound": "hbm", "kernel": "khg_fwd_kernel<0,1> (colour + DWT level 1 + quantiser + histogram, luma)",
+                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "bytes_per_launch": LUMA_FWD_BYTES_PER_PX * px, "avg_launch_ms": round(k_ms, 4)},
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -388,6 +388,36 @@ extern "C" int khg_symbols_dev(khg_ctx* c, const uint8_t* d_r, const uint8_t* d_
     return c->h_res->status;
 }
 
+extern "C" int khg_time_luma_forward_dev(khg_ctx* c, const uint8_t* d_r, const uint8_t* d_g, const uint8_t* d_b,
+                                         int rows, int cols, int lvl, int reps, float* avg_ms, void* stream)
+{
+    int rc = khg_check_image(c, rows, cols);
+    if (rc) return rc;
+    if (lvl < 0 || lvl > 2 || reps < 1 || !avg_ms) return KHG_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    KHG_HIP(hipSetDevice(c->device));
+    KhgWorkspace& ws = c->ws;
+    KHG_HIP(hipMemsetAsync(ws.hist_cnt, 0, 3 * KHG_NBINS * sizeof(uint32_t), st));
+    KHG_HIP(hipMemsetAsync(ws.hist_first, 0xFF, 3 * KHG_NBINS * sizeof(uint32_t), st));
+    KHG_HIP(hipMemsetAsync(ws.res, 0, sizeof(KhgResult), st));
+    KhgFwdGrid gr;
+    KhgFwdArgs a = khg_fwd_args(ws, d_r, d_g, d_b, rows, cols, lvl, 0, 1, nullptr, &gr);
+    hipEvent_t e0, e1;
+    KHG_HIP(hipEventCreate(&e0));
+    KHG_HIP(hipEventCreate(&e1));
+    khg_launch_fwd<KHG_SRC_Y, 1>(a, gr, st);  // warm-up
+    KHG_HIP(hipEventRecord(e0, st));
+    for (int i = 0; i < reps; ++i) khg_launch_fwd<KHG_SRC_Y, 1>(a, gr, st);
+    KHG_HIP(hipEventRecord(e1, st));
+    KHG_HIP(hipEventSynchronize(e1));
+    float ms = 0;
+    KHG_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *avg_ms = ms / reps;
+    return KHG_OK;
+}
+
 extern "C" int khg_synth_dev(uint8_t* d_r, uint8_t* d_g, uint8_t* d_b, int rows, int cols, uint32_t seed,
                              uint32_t index, void* stream)
 {

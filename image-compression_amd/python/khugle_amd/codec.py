@@ -109,6 +109,14 @@ class Codec:
                                       _ptr(qcb), _ptr(qcr), _stream()), "symbols")
         return qy, qcb, qcr
 
+    def time_luma_forward_dev(self, rgb, lvl, reps=10):
+        """Mean duration (ms) of the level-1 luma forward kernel, HIP events on the current stream."""
+        _, h, w = rgb.shape
+        ms = C.c_float(0)
+        _check(self.L.khg_time_luma_forward_dev(self._ctx, _ptr(rgb[0]), _ptr(rgb[1]), _ptr(rgb[2]), h, w, lvl, reps,
+                                                C.byref(ms), _stream()), "time_luma_forward")
+        return ms.value
+
     def synth_dev(self, rows, cols, seed, index, out=None):
         t = self.torch
         if out is None:

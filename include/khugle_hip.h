@@ -93,12 +93,17 @@ int khg_psnr_dev(khg_ctx *ctx, const uint8_t *d_ir, const uint8_t *d_ig, const u
 
 /* ---- parity taps (device pointers, synchronous).  Any output pointer may be NULL.
  * khg_forward_planes_dev: Y/Cb/Cr after the two FWT2D levels (Compress.h:108-114), f64, row-major.
- * khg_symbols_dev: the quantised planes (Compress.h:165-243) as int16, row-major.
- * khg_tables_dev: the (count, symbol) tables (Huffman.h:110-139) of the context's last encode. */
+ * khg_symbols_dev: the quantised planes (Compress.h:165-243) as int16, row-major. */
 int khg_forward_planes_dev(khg_ctx *ctx, const uint8_t *d_r, const uint8_t *d_g, const uint8_t *d_b, int rows,
                            int cols, double *d_y, double *d_cb, double *d_cr, void *stream);
 int khg_symbols_dev(khg_ctx *ctx, const uint8_t *d_r, const uint8_t *d_g, const uint8_t *d_b, int rows, int cols,
                     int lvl, int16_t *d_qy, int16_t *d_qcb, int16_t *d_qcr, void *stream);
+
+/* ---- measurement aid: runs only the level-1 luma forward kernel (colour + DWT level 1 + quantiser +
+ * histogram of the Y plane, the longest-running kernel of the path) `reps` times on `stream`,
+ * bracketed by HIP events recorded on that stream, and returns the mean launch duration. */
+int khg_time_luma_forward_dev(khg_ctx *ctx, const uint8_t *d_r, const uint8_t *d_g, const uint8_t *d_b, int rows,
+                              int cols, int lvl, int reps, float *avg_ms, void *stream);
 
 /* ---- synthetic frames for benchmarks: deterministic integer arithmetic, identical to
  * khugle_amd.synth.synth_frame on the host.  Device planes. */

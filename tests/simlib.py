@@ -1,0 +1,80 @@
+"""Loader of the test-only kernel simulator (tests/sim/khg_sim.cpp, built with -DKHG_SIM)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+SRC = os.path.join(HERE, "sim", "khg_sim.cpp")
+SO = os.path.join(HERE, "sim", "libkhg_sim.so")
+CSRC = os.path.join(ROOT, "image-compression_amd", "csrc")
+
+_u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
+_lib = None
+
+
+def build(force=False):
+    deps = [SRC] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    if force or not os.path.exists(SO) or os.path.getmtime(SO) < max(os.path.getmtime(d) for d in deps):
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-I" + CSRC,
+                               "-o", SO, SRC])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(SO)
+        L.khgsim_encode.argtypes = [_u8p, _u8p, _u8p, C.c_int, C.c_int, C.c_int, _u8p, C.c_size_t,
+                                    C.POINTER(C.c_size_t)]
+        L.khgsim_forward.argtypes = [_u8p, _u8p, _u8p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 6
+        L.khgsim_decode.argtypes = [_u8p, C.c_size_t, C.c_int, C.c_int, _u8p, _u8p, _u8p, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.POINTER(C.c_int)]
+        L.khgsim_ssim.argtypes = [_u8p, _u8p, C.c_int, C.c_int, C.c_void_p]
+        L.khgsim_ssim.restype = C.c_double
+        L.khgsim_synth.argtypes = [_u8p, _u8p, _u8p, C.c_int, C.c_int, C.c_uint32, C.c_uint32]
+        L.khgsim_synth.restype = None
+        _lib = L
+    return _lib
+
+
+def encode(rgb, lvl, cap=None):
+    _, h, w = rgb.shape
+    if cap is None:
+        cap = (36 + h * w * 3 + 3 * 16384 * 8 + 3) // 4 * 4
+    out = np.zeros(cap, np.uint8)
+    n = C.c_size_t(0)
+    rc = lib().khgsim_encode(rgb[0], rgb[1], rgb[2], h, w, lvl, out, cap, C.byref(n))
+    return rc, out[:n.value].tobytes() if rc == 0 else b""
+
+
+def forward(rgb, lvl):
+    _, h, w = rgb.shape
+    y = np.zeros((h, w)); cb = np.zeros((h // 2, w // 2)); cr = np.zeros((h // 2, w // 2))
+    qy = np.zeros((h, w), np.int16); qcb = np.zeros((h // 2, w // 2), np.int16); qcr = np.zeros((h // 2, w // 2), np.int16)
+    rc = lib().khgsim_forward(rgb[0], rgb[1], rgb[2], h, w, lvl, *[a.ctypes.data for a in (y, cb, cr, qy, qcb, qcr)])
+    return rc, (y, cb, cr), (qy, qcb, qcr)
+
+
+def decode(comp, rows, cols):
+    buf = np.frombuffer(comp, np.uint8).copy()
+    out = np.zeros((3, rows, cols), np.uint8)
+    qy = np.zeros((rows, cols), np.int16); qcb = np.zeros((rows // 2, cols // 2), np.int16)
+    qcr = np.zeros((rows // 2, cols // 2), np.int16)
+    passes = C.c_int(0)
+    rc = lib().khgsim_decode(buf, buf.size, rows, cols, out[0], out[1], out[2], qy.ctypes.data, qcb.ctypes.data,
+                             qcr.ctypes.data, C.byref(passes))
+    return rc, out, (qy, qcb, qcr), passes.value
+
+
+def ssim(a, b):
+    a = np.ascontiguousarray(a, np.uint8); b = np.ascontiguousarray(b, np.uint8)
+    return lib().khgsim_ssim(a, b, a.shape[1], a.shape[0], None)
+
+
+def synth(rows, cols, seed, index):
+    out = np.zeros((3, rows, cols), np.uint8)
+    lib().khgsim_synth(out[0], out[1], out[2], rows, cols, seed, index)
+    return out

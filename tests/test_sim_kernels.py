@@ -1,0 +1,78 @@
+"""The HIP kernel bodies, compiled with -DKHG_SIM and run sequentially on the CPU, against the
+oracle: checks indexing, arithmetic order and the launch plan without a GPU.  (The simulator is
+test infrastructure; the product library has no CPU path.)"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import RUN
+import oracle_py as O
+import simlib as S
+import craft
+from khugle_amd import synth_frame
+
+SHAPES = [(8, 8), (16, 24), (24, 16), (64, 64), (264, 520), (520, 264), (256, 512)]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("lvl", [0, 1, 2])
+def test_forward_stages_and_bytes(shape, lvl):
+    rgb = synth_frame(shape[0], shape[1], 3, lvl)
+    rc, coef, q = S.forward(rgb, lvl)
+    assert rc == 0
+    for g, w in zip(coef, O.forward_planes(rgb)):
+        assert np.array_equal(g, w)
+    for g, w in zip(q, O.symbols(rgb, lvl)):
+        assert np.array_equal(g.astype(np.int32), w)
+    rc, comp = S.encode(rgb, lvl)
+    assert rc == 0 and comp == O.encode(rgb, lvl)
+
+
+@pytest.mark.parametrize("name,lvl", [("cat", 1), ("couple", 0), ("library", 2), ("lena", 1), ("baboon", 0)])
+def test_run_images(run_images, name, lvl):
+    rgb = run_images[name]
+    rc, comp = S.encode(rgb, lvl)
+    assert rc == 0 and comp == O.encode(rgb, lvl)
+    rc, out, q, passes = S.decode(comp, rgb.shape[1], rgb.shape[2])
+    assert rc == 0 and passes == 2
+    assert np.array_equal(out, O.decode(comp))
+    assert S.ssim(rgb[0], out[0]) == O.ssim(rgb[0], out[0])
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_decode(shape):
+    rgb = synth_frame(shape[0], shape[1], 4, 1)
+    comp = O.encode(rgb, 1)
+    rc, out, q, passes = S.decode(comp, shape[0], shape[1])
+    assert rc == 0
+    (wq, _) = O.decode_planes(comp)
+    for g, w in zip(q, wq):
+        assert np.array_equal(g.astype(np.int32), w)
+    assert np.array_equal(out, O.decode(comp))
+
+
+def test_decode_reference_files():
+    for ref in ("cat_high", "couple_normal", "library_extreme"):
+        comp = open(os.path.join(RUN, ref + ".comp"), "rb").read()
+        hd = O.peek(comp)
+        rc, out, _, _ = S.decode(comp, hd.h, hd.w)
+        assert rc == 0 and np.array_equal(out, O.decode(comp))
+
+
+def test_decode_fixed_length_codes_takes_extra_passes():
+    comp = craft.fixed_length_comp(512, 512, 1)  # 786432 luma bits = 1536 subsequences = 6 workgroups
+    rc, out, _, passes = S.decode(comp, 512, 512)
+    assert rc == 0 and passes > 2
+    assert np.array_equal(out, O.decode(comp))
+
+
+def test_output_capacity_is_checked():
+    rgb = synth_frame(64, 64, 1, 0)
+    rc, _ = S.encode(rgb, 0, cap=64)
+    assert rc == -2
+
+
+def test_device_synth_twin():
+    for (h, w, seed, idx) in [(16, 24, 2025, 0), (136, 264, 2025, 77)]:
+        assert np.array_equal(S.synth(h, w, seed, idx), synth_frame(h, w, seed, idx))
