@@ -32,10 +32,10 @@ static inline KhgDecArgs khg_dec_args(const KhgWorkspace& ws, const KhgDecWorksp
         d.sym[p] = ws.sym[p];
     }
     d.nblocks = blk;
-    d.arrive[0] = dws.lut + 3 * KHG_LUT_SIZE;
-    d.arrive[1] = d.arrive[0] + blk;
-    d.mismatch = d.arrive[1] + blk;
+    d.blk = dws.blk;
+    d.mismatch = dws.lut + 3 * KHG_LUT_SIZE;
     d.sub = dws.sub;
+    d.masks = dws.masks;
     d.pass = 0;
     return d;
 }

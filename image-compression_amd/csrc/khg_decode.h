@@ -2,29 +2,37 @@
 // parallel Huffman decode.
 //
 // The format has no synchronisation markers (Writer.h:25-32 just concatenates codes), so
-// each plane's stream is cut into 512-bit subsequences, one thread each.  A thread that
-// starts inside a codeword decodes garbage for a few symbols and then falls into step
-// with the true codeword boundaries (Huffman codes self-synchronise), so:
-//   sync pass : every thread decodes from its assumed start to the first codeword boundary
-//               at or after its subsequence's end; a workgroup (256 subsequences) repeats
-//               this, each thread restarting from its predecessor's arrival point, until
-//               nothing changes.  The workgroup's own start comes from the previous
-//               workgroup's arrival in the previous pass; pass p+1 also verifies that every
-//               arrival equals pass p's -- then all starts are exact by induction from the
-//               first workgroup, whose start (bit 0) is exact.
-//   scan      : symbol counts -> output index of every subsequence
-//   write     : every thread decodes its subsequence once more from its exact start and
-//               stores the symbols (Huffman.h:33-55: symbol i lands at raster index i).
+// each plane's stream is cut into 512-bit subsequences, one thread each, 256 per workgroup;
+// a workgroup stages its 16 KiB of stream in LDS.  A thread that starts inside a codeword
+// decodes garbage for a few symbols and then falls into step with the true codeword
+// boundaries (Huffman codes self-synchronise), so:
+//   sync : every thread decodes from its assumed start to the first codeword boundary at or
+//          after its subsequence's end, recording the codeword starts it saw in a 512-bit
+//          map.  Then, until nothing changes, each thread restarts from its predecessor's
+//          arrival point; as soon as it lands on a start its earlier run had already seen,
+//          the rest of that run is known to be right and it stops.
+//   fix  : the first thread of a workgroup started blind; it is re-run from where the
+//          previous workgroup arrived.  If every such re-run rejoins its earlier run, all
+//          starts are exact by induction from the first workgroup (bit 0 is exact);
+//          otherwise the host repeats full sync passes chained through the workgroup
+//          arrivals until they stop changing (fixed-length codes need this).
+//   scan : symbol counts -> output index of every workgroup
+//   write: every thread decodes its subsequence from its exact start and stores the
+//          symbols (Huffman.h:33-55: symbol i lands at raster index i).
 #pragma once
 #include "khg_common.h"
 #include "khg_huffman.h"
 
 enum {
     KHG_SUB_BITS = 512,       // bits per subsequence
+    KHG_SUB_WORDS = KHG_SUB_BITS / 32,
     KHG_DEC_BLOCK = 256,      // subsequences per workgroup
+    KHG_BLK_BITS = KHG_SUB_BITS * KHG_DEC_BLOCK,
+    KHG_STAGE_WORDS = KHG_BLK_BITS / 32 + 4,  // a workgroup's span plus the longest overshoot
+    KHG_STAGE_LDS = KHG_STAGE_WORDS + KHG_STAGE_WORDS / 32 + 1,  // one pad word per 32: threads read 16 words apart
     KHG_LUT_BITS = 12,
     KHG_LUT_SIZE = 1 << KHG_LUT_BITS,
-    KHG_NOT_CONVERGED = 1     // internal status: the host must enqueue another sync pass
+    KHG_NOT_CONVERGED = 1     // internal status: the host must run chained sync passes
 };
 
 // Parsed header plus derived layout, written by khg_dec_header_body.
@@ -41,25 +49,37 @@ struct KhgDecHeader {
 struct KhgSubInfo {
     uint32_t start;  // exact bit position of the first codeword starting in this subsequence
     uint32_t count;  // symbols whose codeword starts in it
-    uint32_t out;    // raster index of the first of them (filled by the scan)
-    uint32_t pad_;
+};
+
+// Per-workgroup record kept between the decode kernels.
+struct KhgBlkInfo {
+    uint32_t arrive[2];   // where the workgroup's last thread arrived, by pass parity
+    uint32_t total;       // symbols starting in the workgroup's span
+    uint32_t out;         // raster index of the first of them (filled by the scan)
+    uint32_t pad_[4];
 };
 
 struct KhgDecWorkspace {
     double* plane[3];   // reconstructed Y / Cb / Cr (f64)
-    uint32_t* lut;      // [3][KHG_LUT_SIZE] first-level decode table, then block arrival arrays
+    uint32_t* lut;      // [3][KHG_LUT_SIZE] first-level decode tables, then the mismatch word
+    KhgBlkInfo* blk;    // per workgroup, planes concatenated
     KhgSubInfo* sub;    // per subsequence, planes concatenated
+    uint32_t* masks;    // [subsequence][KHG_SUB_WORDS] codeword-start maps
     KhgDecHeader* hdr;
 };
 
 struct KhgDecWorkspaceSizes {
-    size_t plane[3], lut, sub;
+    size_t plane[3], lut, sub, blk, masks;
 };
+
+// Decoder limit on a plane's stream: 16 bits per symbol on average.  A Huffman code built from the
+// stored counts averages below log2(K) + 1 <= 15 bits when the stream follows those counts, as every
+// stream written by Writer.h / by this library does; longer streams are rejected (KHG_ERR_RANGE).
+enum { KHG_DEC_MAX_AVG_BITS = 16 };
 
 static inline uint32_t khg_max_subs(uint64_t nsym)
 {
-    // a plane's stream has fewer than 2^31 bits and at most 56 bits per symbol
-    uint64_t bits = nsym * KHG_MAX_CODE_BITS;
+    uint64_t bits = nsym * KHG_DEC_MAX_AVG_BITS;
     if (bits > 0x7FFFFFFFull) bits = 0x7FFFFFFFull;
     return (uint32_t)((bits + KHG_SUB_BITS - 1) / KHG_SUB_BITS);
 }
@@ -77,9 +97,10 @@ struct KhgDecArgs {
     int32_t* tree_root;    // [3]
     uint32_t* big_scratch;
     uint32_t* lut;         // [3][KHG_LUT_SIZE]
-    uint32_t* arrive[2];   // [nblocks] block arrival positions, double-buffered by pass parity
+    KhgBlkInfo* blk;       // [nblocks]
     uint32_t* mismatch;    // [1]
     KhgSubInfo* sub;
+    uint32_t* masks;       // [subsequence][KHG_SUB_WORDS]
     uint32_t sub0[3];      // first subsequence index of each plane (capacity layout)
     uint32_t blk0[3];      // first workgroup index of each plane
     uint32_t nblocks;
@@ -95,8 +116,10 @@ static inline void khg_dec_workspace_sizes(int rows, int cols, KhgDecWorkspaceSi
     s->plane[1] = s->plane[2] = nc * sizeof(double);
     size_t subs = (size_t)khg_max_subs(ny) + 2 * (size_t)khg_max_subs(nc) + 3 * KHG_DEC_BLOCK;
     size_t blocks = subs / KHG_DEC_BLOCK + 4;
-    s->lut = (3 * (size_t)KHG_LUT_SIZE + 2 * blocks + 16) * sizeof(uint32_t);
+    s->lut = (3 * (size_t)KHG_LUT_SIZE + 16) * sizeof(uint32_t);
     s->sub = subs * sizeof(KhgSubInfo);
+    s->blk = blocks * sizeof(KhgBlkInfo);
+    s->masks = subs * KHG_SUB_WORDS * sizeof(uint32_t);
 }
 
 KHG_DEV int32_t khg_load_le32(const uint8_t* p)
@@ -139,7 +162,10 @@ KHG_DEV void khg_dec_header_body(const KhgDecArgs& a)
                     h->k[p] = k[p];
                     // a single-entry table has the empty code: its stream must be empty (Huffman.h:57-68)
                     if (k[p] == 1 && h->nbits[p] != 0) ok = 0;
-                    if (k[p] > 1 && (uint64_t)h->nbits[p] > (uint64_t)a.n[p] * KHG_MAX_CODE_BITS) ok = 0;
+                    if (k[p] > 1 && (uint64_t)h->nbits[p] > (uint64_t)a.n[p] * KHG_DEC_MAX_AVG_BITS) {
+                        ok = 0;
+                        khg_set_status(&a.res->status, -4);
+                    }
                 }
                 if (ok && off > a.len) ok = 0;
             }
@@ -151,7 +177,7 @@ KHG_DEV void khg_dec_header_body(const KhgDecArgs& a)
 }
 
 struct KhgDecTreeSmem {
-    alignas(16) uint32_t w[6 * KHG_TREE_LDS_K];
+    alignas(16) uint32_t w[6 * KHG_TREE_LDS_K + 8];
     int32_t root;
 };
 
@@ -181,23 +207,24 @@ KHG_DEV void khg_dec_tree_body(const KhgDecArgs& a, int bid, KhgDecTreeSmem& sh)
         }
     }
     KHG_BARRIER();
-    uint64_t* heap;
-    uint32_t *nfreq, *parent;
-    if (k <= KHG_TREE_LDS_K) {
-        heap = (uint64_t*)sh.w;
-        nfreq = sh.w + 2 * KHG_TREE_LDS_K;
-        parent = sh.w + 4 * KHG_TREE_LDS_K;
+    if (k <= KHG_TREE_LDS_K) {  // separate copies: LDS vs global address space of the heap arrays
+        KHG_FOR_THREADS(256)
+        {
+            if (tid == 0) {
+                sh.root = khg_tree_build(tcnt, k, (uint64_t*)sh.w + 1, sh.w + 2 * KHG_TREE_LDS_K + 4,
+                                         sh.w + 4 * KHG_TREE_LDS_K + 4, left, right);
+                a.tree_root[bid] = sh.root;
+            }
+        }
     } else {
         uint32_t* g = a.big_scratch + (size_t)bid * 10 * KHG_NBINS;
-        heap = (uint64_t*)g;
-        nfreq = g + 2 * KHG_NBINS;
-        parent = g + 4 * KHG_NBINS;
-    }
-    KHG_FOR_THREADS(256)
-    {
-        if (tid == 0) {
-            sh.root = khg_tree_build(tcnt, k, heap, nfreq, parent, left, right);
-            a.tree_root[bid] = sh.root;
+        KHG_FOR_THREADS(256)
+        {
+            if (tid == 0) {
+                sh.root = khg_tree_build(tcnt, k, (uint64_t*)g + 1, g + 2 * KHG_NBINS + 4, g + 4 * KHG_NBINS + 4, left,
+                                         right);
+                a.tree_root[bid] = sh.root;
+            }
         }
     }
     KHG_BARRIER();
@@ -222,39 +249,63 @@ KHG_DEV void khg_dec_tree_body(const KhgDecArgs& a, int bid, KhgDecTreeSmem& sh)
     }
 }
 
-// ---------------------------------------------------------------- bit reader
+// --------------------------------------------------------------- bit readers
 
-struct KhgBits {
+// Stream bits straight from the file in global memory (used where only a few codewords are read).
+struct KhgBitsG {
     const uint32_t* words;  // file as aligned 32-bit words
     uint64_t base;          // bit offset of the plane's stream in the file
     uint32_t nbits;         // stream length in bits
     uint32_t nwords;        // readable words
+    // 32 stream bits starting at stream position pos, first bit in bit 31 (zeros past the end)
+    KHG_DEV uint32_t peek32(uint32_t pos) const
+    {
+        uint64_t g = base + pos;
+        uint32_t w = (uint32_t)(g >> 5), s = (uint32_t)(g & 31);
+        uint32_t w0 = w < nwords ? khg_bswap32(words[w]) : 0;
+        uint32_t w1 = w + 1 < nwords ? khg_bswap32(words[w + 1]) : 0;
+        return s ? (w0 << s) | (w1 >> (32 - s)) : w0;
+    }
 };
 
-// 32 stream bits starting at stream position pos, first bit in bit 31 (zeros past the end).
-KHG_DEV uint32_t khg_peek32(const KhgBits& b, uint32_t pos)
+// The same view over a workgroup's span staged in LDS as byte-swapped words.
+KHG_DEV uint32_t khg_stage_slot(uint32_t w) { return w + (w >> 5); }
+
+struct KhgBitsL {
+    const uint32_t* stage;  // KHG_STAGE_WORDS words at khg_stage_slot() positions
+    uint32_t bias;          // stream position of bit 31 of stage[0] (may be "negative": wraps, used modulo 2^32)
+    uint32_t nbits;
+    KHG_DEV uint32_t peek32(uint32_t pos) const
+    {
+        uint32_t l = pos - bias;
+        uint32_t w = l >> 5, s = l & 31;
+        uint32_t w0 = w < KHG_STAGE_WORDS ? stage[khg_stage_slot(w)] : 0;
+        uint32_t w1 = w + 1 < KHG_STAGE_WORDS ? stage[khg_stage_slot(w + 1)] : 0;
+        return s ? (w0 << s) | (w1 >> (32 - s)) : w0;
+    }
+};
+
+KHG_DEV int khg_block_plane(const KhgDecArgs& a, uint32_t blk)
 {
-    uint64_t g = b.base + pos;
-    uint32_t w = (uint32_t)(g >> 5), s = (uint32_t)(g & 31);
-    uint32_t w0 = w < b.nwords ? khg_bswap32(b.words[w]) : 0;
-    uint32_t w1 = w + 1 < b.nwords ? khg_bswap32(b.words[w + 1]) : 0;
-    return s ? (w0 << s) | (w1 >> (32 - s)) : w0;
+    return blk >= a.blk0[2] ? 2 : blk >= a.blk0[1] ? 1 : 0;
 }
 
-struct KhgDecLut {
-    uint32_t lut[KHG_LUT_SIZE];
-    uint32_t arrive[KHG_DEC_BLOCK];
-    uint32_t count[KHG_DEC_BLOCK];
-    uint32_t used[KHG_DEC_BLOCK];
-    uint32_t changed[2];
-    uint32_t blk_start;
-};
+KHG_DEV KhgBitsG khg_plane_bits(const KhgDecArgs& a, int p)
+{
+    KhgBitsG b;
+    b.words = (const uint32_t*)a.comp;
+    b.base = 8ull * a.hdr->stream_byte[p];
+    b.nbits = (uint32_t)a.hdr->nbits[p];
+    b.nwords = (uint32_t)(a.len >> 2);
+    return b;
+}
 
 // Decode one codeword at pos.  Returns its length (0 = the stream ends inside it) and symbol.
-KHG_DEV uint32_t khg_decode_one(const KhgBits& b, const uint32_t* lut, const int32_t* left, const int32_t* right,
+template <class Bits>
+KHG_DEV uint32_t khg_decode_one(const Bits& b, const uint32_t* lut, const int32_t* left, const int32_t* right,
                                 const int32_t* tsym, uint32_t pos, int* sym)
 {
-    uint32_t window = khg_peek32(b, pos);
+    uint32_t window = b.peek32(pos);
     uint32_t e = lut[window >> (32 - KHG_LUT_BITS)];
     uint32_t len;
     if (e & 0x80000000u) {
@@ -266,7 +317,7 @@ KHG_DEV uint32_t khg_decode_one(const KhgBits& b, const uint32_t* lut, const int
         len = KHG_LUT_BITS;
         while (left[node] >= 0) {
             if (pos + len >= b.nbits) return 0;
-            uint32_t bit = khg_peek32(b, pos + len) >> 31;
+            uint32_t bit = b.peek32(pos + len) >> 31;
             node = bit ? right[node] : left[node];
             ++len;
         }
@@ -276,64 +327,122 @@ KHG_DEV uint32_t khg_decode_one(const KhgBits& b, const uint32_t* lut, const int
     return len;
 }
 
-// Decode from `start` to the first codeword boundary at or after `end` (or until the stream
-// cannot supply another whole codeword).  Returns the arrival position; *count = symbols decoded.
-KHG_DEV uint32_t khg_decode_span(const KhgBits& b, const uint32_t* lut, const int32_t* left, const int32_t* right,
-                                 const int32_t* tsym, uint32_t start, uint32_t end, uint32_t* count)
+// Codeword-start bitmap of one subsequence: word w of thread t lives at mask[w * stride + t * tstride];
+// position r (0..511) is bit 31 - (r & 31) of word r >> 5.
+struct KhgMaskRef {
+    uint32_t* m;
+    uint32_t wstride;
+    KHG_DEV uint32_t& word(uint32_t w) const { return m[w * wstride]; }
+};
+
+// Decode from `start` (inside the subsequence beginning at sub_begin) until the first codeword
+// boundary at or after `end`.  Codeword starts are recorded in `mask`.  With has_old, `mask`
+// holds the starts of an earlier run of the same subsequence: landing on one of them means the
+// two runs coincide from there on, so the earlier arrival (*arrive on entry) stands and the
+// earlier starts at and after that point are kept and counted.  Returns the arrival position
+// (0xFFFFFFFF: the stream ends inside a codeword) and the number of codewords started.
+template <class Bits>
+KHG_DEV void khg_decode_span(const Bits& b, const uint32_t* lut, const int32_t* left, const int32_t* right,
+                             const int32_t* tsym, uint32_t sub_begin, uint32_t start, uint32_t end, bool has_old,
+                             const KhgMaskRef& mask, uint32_t* arrive, uint32_t* count)
 {
     uint32_t pos = start, n = 0;
+    uint32_t widx = (start - sub_begin) >> 5;
+    for (uint32_t w = 0; w < widx; ++w) mask.word(w) = 0;
+    uint32_t oldw = has_old ? mask.word(widx) : 0, cur = 0;
+    bool exhausted = false;
     while (pos < end) {
+        uint32_t rel = pos - sub_begin, w = rel >> 5;
+        while (widx < w) {
+            mask.word(widx) = cur;
+            ++widx;
+            cur = 0;
+            oldw = has_old ? mask.word(widx) : 0;
+        }
+        uint32_t bit = 0x80000000u >> (rel & 31);
+        if (oldw & bit) {
+            // rejoined the earlier run: keep its starts from here on
+            uint32_t ge = bit | (bit - 1);
+            uint32_t rest = (uint32_t)__builtin_popcount(oldw & ge);
+            mask.word(widx) = cur | (oldw & ge);
+            for (uint32_t w2 = widx + 1; w2 < KHG_SUB_WORDS; ++w2) rest += (uint32_t)__builtin_popcount(mask.word(w2));
+            *count = n + rest;
+            return;  // *arrive unchanged
+        }
         int s;
         uint32_t len = khg_decode_one(b, lut, left, right, tsym, pos, &s);
         if (len == 0) {
-            pos = 0xFFFFFFFFu;  // stream exhausted inside a codeword: nothing starts after this point
+            exhausted = true;
             break;
         }
+        cur |= bit;
         pos += len;
         ++n;
     }
+    mask.word(widx) = cur;
+    for (uint32_t w2 = widx + 1; w2 < KHG_SUB_WORDS; ++w2) mask.word(w2) = 0;
+    *arrive = exhausted ? 0xFFFFFFFFu : pos;
     *count = n;
-    return pos;
 }
 
-KHG_DEV int khg_block_plane(const KhgDecArgs& a, uint32_t blk)
-{
-    return blk >= a.blk0[2] ? 2 : blk >= a.blk0[1] ? 1 : 0;
-}
+struct KhgDecSmem {
+    uint32_t lut[KHG_LUT_SIZE];
+    uint32_t stage[KHG_STAGE_LDS];
+    uint32_t mask[KHG_SUB_WORDS * KHG_DEC_BLOCK];  // word-major: thread t's word w at [w * 256 + t]
+    uint32_t arrive[KHG_DEC_BLOCK];
+    uint32_t count[KHG_DEC_BLOCK];
+    uint32_t used[KHG_DEC_BLOCK];
+    uint32_t grp[16];
+    uint32_t changed[2];
+    uint32_t blk_start;
+};
 
-KHG_DEV KhgBits khg_plane_bits(const KhgDecArgs& a, int p)
+// Stage the LUT and the workgroup's span of the stream (byte-swapped words) in LDS.
+KHG_DEV KhgBitsL khg_dec_stage(const KhgDecArgs& a, int p, uint32_t blk_begin, KhgDecSmem& sh)
 {
-    KhgBits b;
-    b.words = (const uint32_t*)a.comp;
-    b.base = 8ull * a.hdr->stream_byte[p];
-    b.nbits = (uint32_t)a.hdr->nbits[p];
-    b.nwords = (uint32_t)(a.len >> 2);
-    return b;
-}
-
-// One workgroup = 256 consecutive subsequences of one plane.
-KHG_DEV void khg_dec_sync_body(const KhgDecArgs& a, uint32_t blk, KhgDecLut& sh)
-{
-    if (!a.hdr->ok) return;
-    const int p = khg_block_plane(a, blk);
-    const KhgBits bits = khg_plane_bits(a, p);
-    const uint32_t lb = blk - a.blk0[p];                       // block index inside the plane
-    const uint32_t blk_begin = lb * KHG_DEC_BLOCK * KHG_SUB_BITS;
-    if (blk_begin >= bits.nbits && !(lb == 0)) return;         // beyond the stream (block 0 still records zeros)
-    const int32_t* left = a.tree_left + (size_t)p * 2 * KHG_NBINS;
-    const int32_t* right = a.tree_right + (size_t)p * 2 * KHG_NBINS;
-    const int32_t* tsym = a.tab_sym + (size_t)p * KHG_NBINS;
+    const KhgBitsG g = khg_plane_bits(a, p);
     const uint32_t* glut = a.lut + (size_t)p * KHG_LUT_SIZE;
-    const uint32_t* prev = a.arrive[(a.pass + 1) & 1];
-    uint32_t* cur = a.arrive[a.pass & 1];
-
+    const uint64_t gbit = g.base + blk_begin;
+    const uint32_t w0 = (uint32_t)(gbit >> 5);
     KHG_FOR_THREADS(256)
     {
         for (int i = tid; i < KHG_LUT_SIZE; i += 256) sh.lut[i] = glut[i];
+        for (uint32_t i = (uint32_t)tid; i < KHG_STAGE_WORDS; i += 256) {
+            uint32_t w = w0 + i;
+            sh.stage[khg_stage_slot(i)] = w < g.nwords ? khg_bswap32(g.words[w]) : 0;
+        }
+    }
+    KhgBitsL l;
+    l.stage = sh.stage;
+    l.bias = blk_begin - (uint32_t)(gbit & 31);
+    l.nbits = g.nbits;
+    return l;
+}
+
+// One workgroup = 256 consecutive subsequences of one plane.
+// pass 0: the workgroup's first thread starts at the nominal position (exact only for the plane's
+// first workgroup).  pass > 0 (chained passes, only when the fix kernel reported a mismatch): it
+// starts where the previous workgroup arrived in the previous pass, and a changed arrival is counted.
+KHG_DEV void khg_dec_sync_body(const KhgDecArgs& a, uint32_t blk, KhgDecSmem& sh)
+{
+    if (!a.hdr->ok) return;
+    const int p = khg_block_plane(a, blk);
+    const uint32_t nbits = (uint32_t)a.hdr->nbits[p];
+    const uint32_t lb = blk - a.blk0[p];  // workgroup index inside the plane
+    const uint32_t blk_begin = lb * KHG_BLK_BITS;
+    if (blk_begin >= nbits && lb != 0) return;  // beyond the stream (workgroup 0 still records zeros)
+    const int32_t* left = a.tree_left + (size_t)p * 2 * KHG_NBINS;
+    const int32_t* right = a.tree_right + (size_t)p * 2 * KHG_NBINS;
+    const int32_t* tsym = a.tab_sym + (size_t)p * KHG_NBINS;
+    KhgBlkInfo* bi = a.blk + blk;
+    const KhgBitsL bits = khg_dec_stage(a, p, blk_begin, sh);
+
+    KHG_FOR_THREADS(256)
+    {
         if (tid == 0) {
-            uint32_t s = blk_begin;  // pass 0: nominal; later: where the previous workgroup arrived
+            uint32_t s = blk_begin;
             if (lb == 0) s = 0;
-            else if (a.pass > 0) s = prev[blk - 1];
+            else if (a.pass > 0) s = a.blk[blk - 1].arrive[(a.pass + 1) & 1];
             sh.blk_start = s;
             sh.changed[0] = 0;
             sh.changed[1] = 0;
@@ -343,29 +452,30 @@ KHG_DEV void khg_dec_sync_body(const KhgDecArgs& a, uint32_t blk, KhgDecLut& sh)
         sh.count[tid] = 0;
     }
     KHG_BARRIER();
-    // Round r: every thread restarts from its predecessor's current arrival if that differs from
-    // the start it last decoded from.  A correct start propagates at least one thread per round.
+    // Every round, a thread whose predecessor's arrival differs from the start it last decoded
+    // from runs again.  An exact start propagates at least one thread per round.
     for (int round = 0; round <= KHG_DEC_BLOCK; ++round) {
         uint32_t mystart[KHG_NSLOT(256)];
         KHG_FOR_THREADS(256)
         {
-            uint32_t s = tid == 0 ? sh.blk_start : sh.arrive[tid - 1];
-            mystart[KHG_SLOT] = s;
+            mystart[KHG_SLOT] = tid == 0 ? sh.blk_start : sh.arrive[tid - 1];
         }
         KHG_BARRIER();
         KHG_FOR_THREADS(256)
         {
-            uint32_t s = mystart[KHG_SLOT];
-            uint32_t end = blk_begin + ((uint32_t)tid + 1) * KHG_SUB_BITS;
+            const uint32_t s = mystart[KHG_SLOT];
+            const uint32_t sub_begin = blk_begin + (uint32_t)tid * KHG_SUB_BITS;
+            const uint32_t end = sub_begin + KHG_SUB_BITS;
             if (s != sh.used[tid]) {
-                uint32_t cnt = 0, arr;
-                if (s >= bits.nbits) {
-                    arr = s;  // nothing starts in this subsequence
-                } else if (s >= end) {
-                    arr = s;  // cannot happen for SUB_BITS > max code length; kept for safety
+                const bool has_old = sh.used[tid] != 0xFFFFFFFEu && sh.used[tid] < nbits && sh.used[tid] < end;
+                uint32_t cnt = 0, arr = sh.arrive[tid];
+                KhgMaskRef mr = {&sh.mask[tid], KHG_DEC_BLOCK};
+                if (s >= nbits || s >= end) {
+                    arr = s;  // nothing starts in this subsequence (s >= end cannot happen: 512 > longest code)
+                    for (uint32_t w = 0; w < KHG_SUB_WORDS; ++w) mr.word(w) = 0;
                 } else {
-                    arr = khg_decode_span(bits, sh.lut, left, right, tsym, s, end < bits.nbits ? end : bits.nbits, &cnt);
-                    if (arr != 0xFFFFFFFFu && arr < end && arr >= bits.nbits) arr = bits.nbits;
+                    khg_decode_span(bits, sh.lut, left, right, tsym, sub_begin, s, end < nbits ? end : nbits, has_old,
+                                    mr, &arr, &cnt);
                 }
                 sh.used[tid] = s;
                 sh.arrive[tid] = arr;
@@ -375,6 +485,9 @@ KHG_DEV void khg_dec_sync_body(const KhgDecArgs& a, uint32_t blk, KhgDecLut& sh)
         }
         KHG_BARRIER();
         const bool any = sh.changed[round & 1] != 0;
+#ifdef KHG_SIM_STATS
+        if (any) bi->pad_[0] = (uint32_t)round + 1;
+#endif
         KHG_FOR_THREADS(256)
         {
             if (tid == 0) sh.changed[(round + 1) & 1] = 0;
@@ -387,46 +500,110 @@ KHG_DEV void khg_dec_sync_body(const KhgDecArgs& a, uint32_t blk, KhgDecLut& sh)
         KhgSubInfo si;
         si.start = sh.used[tid];
         si.count = sh.count[tid];
-        si.out = 0;
-        si.pad_ = 0;
         a.sub[a.sub0[p] + lb * KHG_DEC_BLOCK + tid] = si;
-        if (tid == KHG_DEC_BLOCK - 1) {
-            uint32_t arr = sh.arrive[tid];
-            if (a.pass > 0 && prev[blk] != arr) khg_atomic_add(a.mismatch, 1u);
-            cur[blk] = arr;
+        if (tid < 16) {
+            uint32_t t = 0;
+            for (int i = 0; i < 16; ++i) t += sh.count[tid * 16 + i];
+            sh.grp[tid] = t;
+        }
+        uint32_t* gm = a.masks + ((size_t)a.sub0[p] + (size_t)lb * KHG_DEC_BLOCK + tid) * KHG_SUB_WORDS;
+        for (int w = 0; w < KHG_SUB_WORDS; ++w) gm[w] = sh.mask[w * KHG_DEC_BLOCK + tid];
+    }
+    KHG_BARRIER();
+    KHG_FOR_THREADS(256)
+    {
+        if (tid == 0) {
+            uint32_t t = 0;
+            for (int i = 0; i < 16; ++i) t += sh.grp[i];
+            bi->total = t;
+            uint32_t arr = sh.arrive[KHG_DEC_BLOCK - 1];
+            if (a.pass > 0 && bi->arrive[(a.pass + 1) & 1] != arr) khg_atomic_add(a.mismatch, 1u);
+            bi->arrive[a.pass & 1] = arr;
+        }
+    }
+}
+
+// After sync pass 0: one thread per workgroup re-runs the workgroup's leading subsequences from
+// where the previous workgroup arrived, subsequence after subsequence, until the run rejoins
+// the speculative one (normally within a few codewords of the first subsequence).  If it walks
+// through the whole workgroup and arrives somewhere else, the speculation failed for the next
+// workgroup too and a mismatch is recorded.
+KHG_DEV void khg_dec_fix_body(const KhgDecArgs& a, uint32_t bid)
+{
+    if (!a.hdr->ok) return;
+    KHG_FOR_THREADS(256)
+    {
+        const uint32_t blk = bid * 256 + (uint32_t)tid;
+        if (blk < a.nblocks) {
+            const int p = khg_block_plane(a, blk);
+            const uint32_t lb = blk - a.blk0[p];
+            const KhgBitsG bits = khg_plane_bits(a, p);
+            const uint32_t blk_begin = lb * KHG_BLK_BITS;
+            if (lb != 0 && blk_begin < bits.nbits) {
+                KhgBlkInfo* bi = a.blk + blk;
+                KhgSubInfo* sub = a.sub + a.sub0[p] + (size_t)lb * KHG_DEC_BLOCK;
+                uint32_t* masks = a.masks + ((size_t)a.sub0[p] + (size_t)lb * KHG_DEC_BLOCK) * KHG_SUB_WORDS;
+                uint32_t s = a.blk[blk - 1].arrive[0];
+                uint32_t total = bi->total;
+                bool joined = false;
+                for (uint32_t t = 0; t < KHG_DEC_BLOCK; ++t) {
+                    if (s == sub[t].start) {
+                        joined = true;
+                        break;
+                    }
+                    const uint32_t sub_begin = blk_begin + t * KHG_SUB_BITS, end = sub_begin + KHG_SUB_BITS;
+                    const uint32_t old_start = sub[t].start, old_cnt = sub[t].count;
+                    const uint32_t old_arr = t + 1 < KHG_DEC_BLOCK ? sub[t + 1].start : bi->arrive[0];
+                    uint32_t arr = old_arr, cnt = 0;
+                    KhgMaskRef mr = {masks + (size_t)t * KHG_SUB_WORDS, 1};
+                    if (s >= bits.nbits || s >= end) {
+                        arr = s;
+                    } else {
+                        const bool has_old = old_start < bits.nbits && old_start < end;
+                        khg_decode_span(bits, a.lut + (size_t)p * KHG_LUT_SIZE, a.tree_left + (size_t)p * 2 * KHG_NBINS,
+                                        a.tree_right + (size_t)p * 2 * KHG_NBINS, a.tab_sym + (size_t)p * KHG_NBINS,
+                                        sub_begin, s, end < bits.nbits ? end : bits.nbits, has_old, mr, &arr, &cnt);
+                    }
+                    sub[t].start = s;
+                    sub[t].count = cnt;
+                    total = total - old_cnt + cnt;
+                    if (arr == old_arr) {
+                        joined = true;
+                        break;
+                    }
+                    s = arr;
+                }
+                bi->total = total;
+                if (!joined) khg_atomic_add(a.mismatch, 1u);
+            }
         }
     }
 }
 
 struct KhgDecScanSmem {
-    uint64_t psum[3][1024];
-    uint32_t nsub[3];
+    uint64_t psum[1024];
 };
 
-// Single workgroup, 1024 threads: output index of every subsequence; zero-fills raster cells
-// past the decoded symbols (Huffman.h:35: the matrix starts zero-initialised).
+// Single workgroup, 1024 threads: raster index of every workgroup's first symbol; zero-fills raster
+// cells past the decoded symbols (Huffman.h:35: the matrix starts zero-initialised).
 KHG_DEV void khg_dec_scan_body(const KhgDecArgs& a, KhgDecScanSmem& sh)
 {
     if (!a.hdr->ok) return;
     KHG_FOR_THREADS(1024)
     {
-        if (tid < 3) {
-            uint32_t nb = (uint32_t)a.hdr->nbits[tid];
-            sh.nsub[tid] = (nb + KHG_SUB_BITS - 1) / KHG_SUB_BITS;
-        }
         if (tid == 0 && a.mismatch[0] != 0) khg_set_status(&a.res->status, KHG_NOT_CONVERGED);
     }
-    KHG_BARRIER();
     for (int p = 0; p < 3; ++p) {
-        const uint32_t ns = sh.nsub[p];
-        const uint32_t per = (ns + 1023) / 1024;
-        KhgSubInfo* sub = a.sub + a.sub0[p];
+        const uint32_t nbits = (uint32_t)a.hdr->nbits[p];
+        const uint32_t nb = (nbits + KHG_BLK_BITS - 1) / KHG_BLK_BITS;  // active workgroups of this plane
+        const uint32_t per = (nb + 1023) / 1024;
+        KhgBlkInfo* blk = a.blk + a.blk0[p];
         KHG_FOR_THREADS(1024)
         {
             uint64_t s = 0;
-            uint32_t c0 = (uint32_t)tid * per, c1 = c0 + per < ns ? c0 + per : ns;
-            for (uint32_t c = c0; c < c1; ++c) s += sub[c].count;
-            sh.psum[p][tid] = s;
+            uint32_t c0 = (uint32_t)tid * per, c1 = c0 + per < nb ? c0 + per : nb;
+            for (uint32_t c = c0; c < c1; ++c) s += blk[c].total;
+            sh.psum[tid] = s;
         }
         KHG_BARRIER();
         KHG_FOR_THREADS(1024)
@@ -434,8 +611,8 @@ KHG_DEV void khg_dec_scan_body(const KhgDecArgs& a, KhgDecScanSmem& sh)
             if (tid == 0) {
                 uint64_t run = 0;
                 for (int t = 0; t < 1024; ++t) {
-                    uint64_t v = sh.psum[p][t];
-                    sh.psum[p][t] = run;
+                    uint64_t v = sh.psum[t];
+                    sh.psum[t] = run;
                     run += v;
                 }
                 if (run > a.n[p]) khg_set_status(&a.res->status, -3);  // the reference would write out of bounds
@@ -445,11 +622,11 @@ KHG_DEV void khg_dec_scan_body(const KhgDecArgs& a, KhgDecScanSmem& sh)
         KHG_BARRIER();
         KHG_FOR_THREADS(1024)
         {
-            uint32_t c0 = (uint32_t)tid * per, c1 = c0 + per < ns ? c0 + per : ns;
-            uint64_t run = sh.psum[p][tid];
+            uint32_t c0 = (uint32_t)tid * per, c1 = c0 + per < nb ? c0 + per : nb;
+            uint64_t run = sh.psum[tid];
             for (uint32_t c = c0; c < c1; ++c) {
-                sub[c].out = (uint32_t)(run > 0xFFFFFFFFull ? 0xFFFFFFFFull : run);
-                run += sub[c].count;
+                blk[c].out = (uint32_t)(run > 0xFFFFFFFFull ? 0xFFFFFFFFull : run);
+                run += blk[c].total;
             }
             uint32_t decoded = (uint32_t)a.res->bits[p];
             for (uint32_t i = decoded + (uint32_t)tid; i < a.n[p]; i += 1024) a.sym[p][i] = 0;
@@ -459,34 +636,49 @@ KHG_DEV void khg_dec_scan_body(const KhgDecArgs& a, KhgDecScanSmem& sh)
 }
 
 // One workgroup = 256 subsequences: decode each from its exact start and store the symbols.
-KHG_DEV void khg_dec_write_body(const KhgDecArgs& a, uint32_t blk, KhgDecLut& sh)
+KHG_DEV void khg_dec_write_body(const KhgDecArgs& a, uint32_t blk, KhgDecSmem& sh)
 {
     if (!a.hdr->ok || a.res->status != 0) return;
     const int p = khg_block_plane(a, blk);
-    const KhgBits bits = khg_plane_bits(a, p);
+    const uint32_t nbits = (uint32_t)a.hdr->nbits[p];
     const uint32_t lb = blk - a.blk0[p];
-    const uint32_t blk_begin = lb * KHG_DEC_BLOCK * KHG_SUB_BITS;
-    if (blk_begin >= bits.nbits) return;
+    const uint32_t blk_begin = lb * KHG_BLK_BITS;
+    if (blk_begin >= nbits) return;
     const int32_t* left = a.tree_left + (size_t)p * 2 * KHG_NBINS;
     const int32_t* right = a.tree_right + (size_t)p * 2 * KHG_NBINS;
     const int32_t* tsym = a.tab_sym + (size_t)p * KHG_NBINS;
-    const uint32_t* glut = a.lut + (size_t)p * KHG_LUT_SIZE;
+    const KhgSubInfo* sub = a.sub + a.sub0[p] + (size_t)lb * KHG_DEC_BLOCK;
+    const KhgBitsL bits = khg_dec_stage(a, p, blk_begin, sh);
     KHG_FOR_THREADS(256)
     {
-        for (int i = tid; i < KHG_LUT_SIZE; i += 256) sh.lut[i] = glut[i];
+        sh.used[tid] = sub[tid].start;
+        sh.count[tid] = sub[tid].count;
     }
     KHG_BARRIER();
     KHG_FOR_THREADS(256)
     {
-        KhgSubInfo si = a.sub[a.sub0[p] + lb * KHG_DEC_BLOCK + tid];
-        uint32_t pos = si.start;
+        if (tid < 16) {  // exclusive scan of the counts inside each group of 16 threads
+            uint32_t run = 0;
+            for (int i = 0; i < 16; ++i) {
+                sh.arrive[tid * 16 + i] = run;
+                run += sh.count[tid * 16 + i];
+            }
+            sh.grp[tid] = run;
+        }
+    }
+    KHG_BARRIER();
+    KHG_FOR_THREADS(256)
+    {
+        uint32_t o = a.blk[blk].out + sh.arrive[tid];
+        for (int g = 0; g < (tid >> 4); ++g) o += sh.grp[g];
+        uint32_t pos = sh.used[tid];
+        const uint32_t cnt = sh.count[tid];
         int16_t* q = a.sym[p];
-        for (uint32_t i = 0; i < si.count; ++i) {
+        for (uint32_t i = 0; i < cnt; ++i) {
             int s;
             uint32_t len = khg_decode_one(bits, sh.lut, left, right, tsym, pos, &s);
             if (len == 0) break;
-            uint32_t o = si.out + i;
-            if (o < a.n[p]) q[o] = (int16_t)s;
+            if (o + i < a.n[p]) q[o + i] = (int16_t)s;
             pos += len;
         }
     }

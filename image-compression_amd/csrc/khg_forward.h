@@ -96,8 +96,15 @@ KHG_DEV double khg_fwd_load(const KhgFwdArgs& a, int gy, int gx)
     return R * 0.5 + G * -0.41869 + B * -0.08131;
 }
 
+// Per-thread counts and first raster indices of the symbols -1, 0, +1.  These make up almost all
+// detail-band symbols; counting them in registers keeps 64 lanes from hammering one LDS word.
+struct KhgHot {
+    uint32_t cm, c0, cp;
+    uint32_t fm, f0, fp;
+};
+
 // Quantise one coefficient, store the symbol and count it (Compress.h:218-219, Huffman.h:110-139).
-KHG_DEV void khg_quant_store(const KhgFwdArgs& a, KhgFwdSmem& sh, double c, int band, int y, int x)
+KHG_DEV void khg_quant_store(const KhgFwdArgs& a, KhgFwdSmem& sh, KhgHot& hot, double c, int band, int y, int x)
 {
     double div = khg_divisor(a.q, band, x, y, a.lvl);
     int q = (int)round(c / div);
@@ -107,6 +114,15 @@ KHG_DEV void khg_quant_store(const KhgFwdArgs& a, KhgFwdSmem& sh, double c, int 
     }
     uint32_t raster = (uint32_t)y * (uint32_t)a.sym_pitch + (uint32_t)x;
     a.sym[raster] = (int16_t)q;
+    if ((unsigned)(q + 1) <= 2u) {
+        hot.cm += q == -1;
+        hot.c0 += q == 0;
+        hot.cp += q == 1;
+        hot.fm = (q == -1 && raster < hot.fm) ? raster : hot.fm;
+        hot.f0 = (q == 0 && raster < hot.f0) ? raster : hot.f0;
+        hot.fp = (q == 1 && raster < hot.fp) ? raster : hot.fp;
+        return;
+    }
     int l = q + KHG_LHIST_BIAS;
     if ((unsigned)l < (unsigned)KHG_LHIST) {
         khg_atomic_add(&sh.cnt[l], 1u);
@@ -131,10 +147,13 @@ KHG_DEV void khg_fwd_strip_body(const KhgFwdArgs& a, int bid, KhgFwdSmem& sh)
     const int hh = a.ph / 2, hw = a.pw / 2;
 
     KhgLift cs[KHG_NSLOT(256)];
+    KhgHot hots[KHG_NSLOT(256)];
     KHG_FOR_THREADS(256)
     {
         KhgLift z = {0, 0, 0, 0, 0};
         cs[KHG_SLOT] = z;
+        KhgHot hz = {0, 0, 0, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+        hots[KHG_SLOT] = hz;
         for (int i = tid; i < KHG_LHIST; i += 256) {
             sh.cnt[i] = 0;
             sh.first[i] = 0xFFFFFFFFu;
@@ -153,6 +172,7 @@ KHG_DEV void khg_fwd_strip_body(const KhgFwdArgs& a, int bid, KhgFwdSmem& sh)
                 const int xq = (x0 >> 1) + tt;
                 const int xo = half ? hw + xq : xq;  // packed output column
                 KhgLift st = cs[KHG_SLOT];
+                KhgHot hot = hots[KHG_SLOT];
                 for (int rr = 0; rr < KHG_BATCH; rr += 2) {
                     double en = sh.B[rr * KHG_B_PITCH + tid];
                     double on = sh.B[(rr + 1) * KHG_B_PITCH + tid];
@@ -168,23 +188,24 @@ KHG_DEV void khg_fwd_strip_body(const KhgFwdArgs& a, int bid, KhgFwdSmem& sh)
                         if (LEVEL == 1) {
                             if (half == 0) {
                                 a.ll[(size_t)k * a.ll_pitch + xq] = lo;
-                                khg_quant_store(a, sh, hi, 5, hh + k, xo);
+                                khg_quant_store(a, sh, hot, hi, 5, hh + k, xo);
                             } else {
-                                khg_quant_store(a, sh, lo, 4, k, xo);
-                                khg_quant_store(a, sh, hi, 6, hh + k, xo);
+                                khg_quant_store(a, sh, hot, lo, 4, k, xo);
+                                khg_quant_store(a, sh, hot, hi, 6, hh + k, xo);
                             }
                         } else {
                             if (half == 0) {
-                                khg_quant_store(a, sh, lo, 0, k, xo);
-                                khg_quant_store(a, sh, hi, 2, hh + k, xo);
+                                khg_quant_store(a, sh, hot, lo, 0, k, xo);
+                                khg_quant_store(a, sh, hot, hi, 2, hh + k, xo);
                             } else {
-                                khg_quant_store(a, sh, lo, 1, k, xo);
-                                khg_quant_store(a, sh, hi, 3, hh + k, xo);
+                                khg_quant_store(a, sh, hot, lo, 1, k, xo);
+                                khg_quant_store(a, sh, hot, hi, 3, hh + k, xo);
                             }
                         }
                     }
                 }
                 cs[KHG_SLOT] = st;
+                hots[KHG_SLOT] = hot;
             }
             if (b < nb) {
                 // ---- load phase of batch b
@@ -220,6 +241,23 @@ KHG_UNROLL
         }
     }
 
+    KHG_FOR_THREADS(256)
+    {
+        const KhgHot hot = hots[KHG_SLOT];
+        if (hot.cm) {
+            khg_atomic_add(&sh.cnt[KHG_LHIST_BIAS - 1], hot.cm);
+            khg_atomic_min(&sh.first[KHG_LHIST_BIAS - 1], hot.fm);
+        }
+        if (hot.c0) {
+            khg_atomic_add(&sh.cnt[KHG_LHIST_BIAS], hot.c0);
+            khg_atomic_min(&sh.first[KHG_LHIST_BIAS], hot.f0);
+        }
+        if (hot.cp) {
+            khg_atomic_add(&sh.cnt[KHG_LHIST_BIAS + 1], hot.cp);
+            khg_atomic_min(&sh.first[KHG_LHIST_BIAS + 1], hot.fp);
+        }
+    }
+    KHG_BARRIER();
     KHG_FOR_THREADS(256)
     {
         for (int i = tid; i < KHG_LHIST; i += 256) {

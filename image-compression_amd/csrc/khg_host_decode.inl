@@ -88,7 +88,7 @@ extern "C" int khg_decode_dev(khg_ctx* c, const uint8_t* d_comp, size_t len, int
     hipLaunchKernelGGL(khg_dec_header_kernel, dim3(1), dim3(256), 0, st, call.d);
     hipLaunchKernelGGL(khg_dec_tree_kernel, dim3(3), dim3(256), 0, st, call.d);
     khg_launch_sync_pass(call.d, 0, st);
-    khg_launch_sync_pass(call.d, 1, st);
+    hipLaunchKernelGGL(khg_dec_fix_kernel, dim3((call.d.nblocks + 255) / 256), dim3(256), 0, st, call.d);
     hipLaunchKernelGGL(khg_dec_scan_kernel, dim3(1), dim3(1024), 0, st, call.d);
     rc = khg_enqueue_decode_tail(c, call);
     if (rc) return rc;
@@ -97,9 +97,9 @@ extern "C" int khg_decode_dev(khg_ctx* c, const uint8_t* d_comp, size_t len, int
     return KHG_OK;
 }
 
-// Waits for the last decode.  If the two speculative synchronisation passes did not agree
-// (a workgroup's 131072-bit span never resynchronised: e.g. fixed-length codes), more passes
-// are run here until every arrival is confirmed, then the tail is re-enqueued.
+// Waits for the last decode.  If a workgroup's first thread, re-run from its exact start, did not
+// rejoin its speculative run (e.g. fixed-length codes never resynchronise), chained sync passes
+// are run here until no workgroup's arrival changes any more, then the tail is re-enqueued.
 static int khg_finish_decode(khg_ctx* c)
 {
     KHG_HIP(hipEventSynchronize(c->done));
@@ -107,7 +107,7 @@ static int khg_finish_decode(khg_ctx* c)
     if (status != KHG_NOT_CONVERGED) return status;
     KhgDecodeCall& call = c->dec_call;
     hipStream_t st = call.st;
-    for (uint32_t pass = 2; pass < call.d.nblocks + 3; ++pass) {
+    for (uint32_t pass = 1; pass < call.d.nblocks + 3; ++pass) {
         KHG_HIP(hipMemsetAsync(c->ws.res, 0, sizeof(KhgResult), st));
         KHG_HIP(hipMemsetAsync(call.d.mismatch, 0, sizeof(uint32_t), st));
         khg_launch_sync_pass(call.d, (int)pass, st);

@@ -41,6 +41,10 @@ struct KhgTableSmem {
     int32_t root;
 };
 
+struct alignas(16) KhgPair {
+    uint64_t a, b;
+};
+
 // Heap entry: freq in the high word, node id in the low word.  Compare (Huffman.h:25-31) looks at freq only.
 KHG_DEV bool khg_heap_comp(uint64_t l, uint64_t r) { return (uint32_t)(l >> 32) > (uint32_t)(r >> 32); }
 
@@ -67,8 +71,14 @@ KHG_DEV uint64_t khg_heap_pop(uint64_t* heap, int& n)
         int hole = 0, child = 0;
         while (child < (len - 1) / 2) {
             child = 2 * (child + 1);
-            if (khg_heap_comp(heap[child], heap[child - 1])) child--;
-            heap[hole] = heap[child];
+            // heap[] starts 8 bytes past a 16-byte boundary, so the pair (child-1, child) is one aligned 16-byte load
+            const KhgPair pr = *(const KhgPair*)&heap[child - 1];
+            uint64_t pick = pr.b;
+            if (khg_heap_comp(pr.b, pr.a)) {
+                child--;
+                pick = pr.a;
+            }
+            heap[hole] = pick;
             hole = child;
         }
         if ((len & 1) == 0 && child == (len - 2) / 2) {
@@ -177,35 +187,48 @@ KHG_DEV void khg_table_body(const KhgTableArgs& a, int bid, KhgTableSmem& sh)
     }
     KHG_BARRIER();  // table complete (global), entry list dead: LDS is reused below
 
-    uint64_t* heap;
-    uint32_t *nfreq, *parent;
+    // Two copies of the sequential part so the compiler sees which address space each one walks
+    // (LDS for ordinary tables, global scratch for tables above KHG_TREE_LDS_K entries).
     if (k <= KHG_TREE_LDS_K) {
-        heap = (uint64_t*)sh.w;                       // [4096] u64  = 8192 words
-        nfreq = sh.w + 2 * KHG_TREE_LDS_K;            // [8192]
-        parent = sh.w + 4 * KHG_TREE_LDS_K;           // [8192]
+        uint64_t* heap = (uint64_t*)sh.w + 1;               // [4096] u64, element 0 at byte 8 (see khg_heap_pop)
+        uint32_t* nfreq = sh.w + 2 * KHG_TREE_LDS_K + 4;    // [8192]
+        uint32_t* parent = sh.w + 4 * KHG_TREE_LDS_K + 4;   // [8192]
+        KHG_FOR_THREADS(256)
+        {
+            if (tid == 0) {
+                if (k == 0) {
+                    khg_set_status(a.status, -3);
+                    sh.root = 0;
+                } else {
+                    sh.root = khg_tree_build(tcnt, k, heap, nfreq, parent, left, right);
+                }
+                a.tree_root[bid] = sh.root;
+            }
+        }
+        KHG_BARRIER();
+        KHG_FOR_THREADS(256)
+        {
+            const int root = sh.root;
+            for (int i = tid; i < k; i += 256) ctab[tsym[i] + KHG_SYM_BIAS] = khg_leaf_code(parent, i, root, a.status);
+        }
     } else {
         uint32_t* g = a.big_scratch + (size_t)bid * 10 * KHG_NBINS;
-        heap = (uint64_t*)g;                          // [16384] u64
-        nfreq = g + 2 * KHG_NBINS;                    // [32768]
-        parent = g + 4 * KHG_NBINS;                   // [32768]
-    }
-    KHG_FOR_THREADS(256)
-    {
-        if (tid == 0) {
-            if (k == 0) {
-                khg_set_status(a.status, -3);
-                sh.root = 0;
-            } else {
+        uint64_t* heap = (uint64_t*)g + 1;                  // [16384] u64, element 0 at byte 8
+        uint32_t* nfreq = g + 2 * KHG_NBINS + 4;            // [32768]
+        uint32_t* parent = g + 4 * KHG_NBINS + 4;           // [32768]
+        KHG_FOR_THREADS(256)
+        {
+            if (tid == 0) {
                 sh.root = khg_tree_build(tcnt, k, heap, nfreq, parent, left, right);
+                a.tree_root[bid] = sh.root;
             }
-            a.tree_root[bid] = sh.root;
         }
-    }
-    KHG_BARRIER();
-    KHG_FOR_THREADS(256)
-    {
-        const int root = sh.root;
-        for (int i = tid; i < k; i += 256) ctab[tsym[i] + KHG_SYM_BIAS] = khg_leaf_code(parent, i, root, a.status);
+        KHG_BARRIER();
+        KHG_FOR_THREADS(256)
+        {
+            const int root = sh.root;
+            for (int i = tid; i < k; i += 256) ctab[tsym[i] + KHG_SYM_BIAS] = khg_leaf_code(parent, i, root, a.status);
+        }
     }
 }
 

@@ -112,14 +112,20 @@ KHG_DEV void khg_inv_strip_body(const KhgInvArgs& a, int bid, KhgInvSmem& sh)
                 const int rx = khg_reflect(2 * ((x0 >> 1) - 2 + tt) + half, a.pw);  // natural column, parity = half
                 const int xo = (rx >> 1) + (half ? hw : 0);
                 KhgILift st = cs[KHG_SLOT];
+                // all loads of the batch first (independent, so their latencies overlap), then the lifting chain
+                double lo[KHG_IBATCH], hi[KHG_IBATCH];
+                KHG_UNROLL
                 for (int s = 0; s < KHG_IBATCH; ++s) {
                     int j = k0 - 2 + b * KHG_IBATCH + s;  // row pair fed in this step
                     int ye = khg_reflect(2 * j, a.ph) >> 1;
                     int yo = hh + (khg_reflect(2 * j + 1, a.ph) >> 1);
-                    double lo = khg_inv_load<LEVEL>(a, qc, lvl, ye, xo, hh, hw);
-                    double hi = khg_inv_load<LEVEL>(a, qc, lvl, yo, xo, hh, hw);
+                    lo[s] = khg_inv_load<LEVEL>(a, qc, lvl, ye, xo, hh, hw);
+                    hi[s] = khg_inv_load<LEVEL>(a, qc, lvl, yo, xo, hh, hw);
+                }
+                KHG_UNROLL
+                for (int s = 0; s < KHG_IBATCH; ++s) {
                     double xe, xod;
-                    khg_inv_step(st, lo, hi, xe, xod);
+                    khg_inv_step(st, lo[s], hi[s], xe, xod);
                     sh.T[(2 * s) * KHG_T_PITCH + tid] = xe;
                     sh.T[(2 * s + 1) * KHG_T_PITCH + tid] = xod;
                 }
@@ -171,13 +177,17 @@ KHG_DEV uint8_t khg_clamp_u8(double v)
 
 KHG_DEV void khg_rgb_body(const KhgRgbArgs& a, uint32_t bid, uint32_t nblk)
 {
-    const size_t quads = (size_t)a.rows * a.cols / 4;
     const int cw = a.cols / 2;
+    const uint32_t qrow = (uint32_t)a.cols / 4;               // quads per row
+    const uint32_t per = (qrow + 255) / 256;                  // quads of one row handled per thread
     KHG_FOR_THREADS(256)
     {
-        for (size_t qd = (size_t)bid * 256 + tid; qd < quads; qd += (size_t)nblk * 256) {
-            size_t p = qd * 4;
-            int yy = (int)(p / (size_t)a.cols), xx = (int)(p - (size_t)yy * a.cols);
+      for (uint32_t yy = bid; yy < (uint32_t)a.rows; yy += nblk)    // one row per workgroup step
+        for (uint32_t k = 0; k < per; ++k) {
+            uint32_t qx = k * 256 + (uint32_t)tid;
+            if (qx >= qrow) break;
+            uint32_t xx = qx * 4;
+            size_t p = (size_t)yy * a.cols + xx;
             uint32_t pr = 0, pg = 0, pb = 0;
             for (int i = 0; i < 4; ++i) {
                 double Y = a.y[p + i];

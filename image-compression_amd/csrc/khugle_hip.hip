@@ -69,8 +69,13 @@ __global__ __launch_bounds__(256) void khg_dec_tree_kernel(KhgDecArgs a)
 
 __global__ __launch_bounds__(256) void khg_dec_sync_kernel(KhgDecArgs a)
 {
-    __shared__ KhgDecLut sh;
+    __shared__ KhgDecSmem sh;
     khg_dec_sync_body(a, blockIdx.x, sh);
+}
+
+__global__ __launch_bounds__(256) void khg_dec_fix_kernel(KhgDecArgs a)
+{
+    khg_dec_fix_body(a, blockIdx.x);
 }
 
 __global__ __launch_bounds__(1024) void khg_dec_scan_kernel(KhgDecArgs a)
@@ -81,7 +86,7 @@ __global__ __launch_bounds__(1024) void khg_dec_scan_kernel(KhgDecArgs a)
 
 __global__ __launch_bounds__(256) void khg_dec_write_kernel(KhgDecArgs a)
 {
-    __shared__ KhgDecLut sh;
+    __shared__ KhgDecSmem sh;
     khg_dec_write_body(a, blockIdx.x, sh);
 }
 
@@ -194,7 +199,7 @@ extern "C" int khg_ctx_create(int device, int max_rows, int max_cols, khg_ctx** 
     size_t o_cb = take(s.chunk_bits), o_co = take(s.chunk_off), o_res = take(sizeof(KhgResult));
     size_t o_plane[3];
     for (int p = 0; p < 3; ++p) o_plane[p] = take(ds.plane[p]);
-    size_t o_lut = take(ds.lut), o_sub = take(ds.sub), o_hdr = take(sizeof(KhgDecHeader));
+    size_t o_lut = take(ds.lut), o_sub = take(ds.sub), o_blk = take(ds.blk), o_masks = take(ds.masks), o_hdr = take(sizeof(KhgDecHeader));
     size_t o_ssim = take(nblk * sizeof(double)), o_sse = take(64);
     c->slab_bytes = total;
     if (hipMalloc(&c->slab, total) != hipSuccess) { delete c; return KHG_ERR_NOMEM; }
@@ -209,6 +214,8 @@ extern "C" int khg_ctx_create(int device, int max_rows, int max_cols, khg_ctx** 
     for (int p = 0; p < 3; ++p) c->dws.plane[p] = (double*)(base + o_plane[p]);
     c->dws.lut = (uint32_t*)(base + o_lut);
     c->dws.sub = (KhgSubInfo*)(base + o_sub);
+    c->dws.blk = (KhgBlkInfo*)(base + o_blk);
+    c->dws.masks = (uint32_t*)(base + o_masks);
     c->dws.hdr = (KhgDecHeader*)(base + o_hdr);
     c->ssim_blocks = (double*)(base + o_ssim);
     c->sse = (unsigned long long*)(base + o_sse);

@@ -38,6 +38,8 @@ struct SimWs {
         for (int p = 0; p < 3; ++p) dws.plane[p] = alloc<double>(d.plane[p]);
         dws.lut = alloc<uint32_t>(d.lut);
         dws.sub = alloc<KhgSubInfo>(d.sub);
+        dws.blk = alloc<KhgBlkInfo>(d.blk);
+        dws.masks = alloc<uint32_t>(d.masks);
         dws.hdr = alloc<KhgDecHeader>(sizeof(KhgDecHeader));
     }
     KhgDecWorkspace dws;
@@ -119,16 +121,20 @@ int khgsim_decode(const uint8_t* comp, size_t len, int rows, int cols, uint8_t* 
     KhgDecTreeSmem* tsh = new KhgDecTreeSmem;
     for (int p = 0; p < 3; ++p) khg_dec_tree_body(d, p, *tsh);
     delete tsh;
-    KhgDecLut* lsh = new KhgDecLut;
+    KhgDecSmem* lsh = new KhgDecSmem;
     KhgDecScanSmem* ssh = new KhgDecScanSmem;
     int pass = 0;
-    for (;; ++pass) {
-        if (pass >= 2) { S.ws.res->status = 0; d.mismatch[0] = 0; }
+    d.pass = 0;
+    for (uint32_t b_ = 0; b_ < d.nblocks; ++b_) khg_dec_sync_body(d, b_, *lsh);
+    for (uint32_t b_ = 0; b_ < (d.nblocks + 255) / 256; ++b_) khg_dec_fix_body(d, b_);
+    khg_dec_scan_body(d, *ssh);
+    while (S.ws.res->status == KHG_NOT_CONVERGED && pass <= (int)d.nblocks + 3) {
+        ++pass;
+        S.ws.res->status = 0;
+        d.mismatch[0] = 0;
         d.pass = pass;
         for (uint32_t b_ = 0; b_ < d.nblocks; ++b_) khg_dec_sync_body(d, b_, *lsh);
-        if (pass == 0) continue;
         khg_dec_scan_body(d, *ssh);
-        if (S.ws.res->status != KHG_NOT_CONVERGED || pass > (int)d.nblocks + 3) break;
     }
     if (passes_used) *passes_used = pass + 1;
     for (uint32_t b_ = 0; b_ < d.nblocks; ++b_) khg_dec_write_body(d, b_, *lsh);
