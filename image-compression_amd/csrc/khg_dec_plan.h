@@ -26,17 +26,12 @@ static inline KhgDecArgs khg_dec_args(const KhgWorkspace& ws, const KhgDecWorksp
     uint32_t blk = 0;
     for (int p = 0; p < 3; ++p) {
         d.blk0[p] = blk;
-        d.sub0[p] = blk * KHG_DEC_BLOCK;
-        blk += (khg_max_subs(d.n[p]) + KHG_DEC_BLOCK - 1) / KHG_DEC_BLOCK;
-        if (blk == d.blk0[p]) blk++;  // at least one workgroup per plane
+        blk += khg_max_blocks(d.n[p]);
         d.sym[p] = ws.sym[p];
     }
     d.nblocks = blk;
     d.blk = dws.blk;
-    d.mismatch = dws.lut + 3 * KHG_LUT_SIZE;
-    d.sub = dws.sub;
-    d.masks = dws.masks;
-    d.pass = 0;
+    d.submap = dws.submap;
     return d;
 }
 

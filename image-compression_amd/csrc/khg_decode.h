@@ -1,24 +1,24 @@
-// khg_decode.h -- .comp header parsing, tree rebuild, and chunked self-synchronising
-// parallel Huffman decode.
+// khg_decode.h -- .comp header parsing, tree rebuild, and chunked parallel Huffman decode.
 //
-// The format has no synchronisation markers (Writer.h:25-32 just concatenates codes), so
-// each plane's stream is cut into 512-bit subsequences, one thread each, 256 per workgroup;
-// a workgroup stages its 16 KiB of stream in LDS.  A thread that starts inside a codeword
-// decodes garbage for a few symbols and then falls into step with the true codeword
-// boundaries (Huffman codes self-synchronise), so:
-//   sync : every thread decodes from its assumed start to the first codeword boundary at or
-//          after its subsequence's end, recording the codeword starts it saw in a 512-bit
-//          map.  Then, until nothing changes, each thread restarts from its predecessor's
-//          arrival point; as soon as it lands on a start its earlier run had already seen,
-//          the rest of that run is known to be right and it stops.
-//   fix  : the first thread of a workgroup started blind; it is re-run from where the
-//          previous workgroup arrived.  If every such re-run rejoins its earlier run, all
-//          starts are exact by induction from the first workgroup (bit 0 is exact);
-//          otherwise the host repeats full sync passes chained through the workgroup
-//          arrivals until they stop changing (fixed-length codes need this).
-//   scan : symbol counts -> output index of every workgroup
-//   write: every thread decodes its subsequence from its exact start and stores the
-//          symbols (Huffman.h:33-55: symbol i lands at raster index i).
+// The format has no synchronisation markers (Writer.h:25-32 just concatenates codes), so the
+// first codeword of a chunk of the stream starts at an unknown offset.  Each plane's stream is
+// cut into 512-bit subsequences (one thread each, 256 per workgroup, staged in LDS).  The first
+// codeword that starts inside a subsequence starts at one of its first M bits, M = the longest
+// code of the plane.  Instead of guessing, a thread works out, for EVERY start offset o < M,
+// where a decoder that starts there arrives in the next subsequence and how many codewords it
+// decodes on the way:
+//   map   : per subsequence, offset -> (arrival offset, count).  Offsets whose first codeword
+//           lands on another offset < M reuse that offset's entry; the others run on.  The first
+//           such run records the codeword starts it sees in a 512-bit map; every later run
+//           stops as soon as it lands on one of them (Huffman codes self-synchronise, so this
+//           is normally within a few codewords; a fixed-length stretch costs one full run per
+//           residue instead).  The workgroup then composes its 256 maps into one.
+//   chain : one thread per plane walks the workgroup maps from bit 0: exact start offset and
+//           output index of every workgroup.
+//   write : every workgroup walks its subsequence maps from its exact start, and every thread
+//           decodes its subsequence from its exact start and stores the symbols
+//           (Huffman.h:33-55: symbol i lands at raster index i).
+// Nothing is speculative: the result is exact for any code.
 #pragma once
 #include "khg_common.h"
 #include "khg_huffman.h"
@@ -32,44 +32,9 @@ enum {
     KHG_STAGE_LDS = KHG_STAGE_WORDS + KHG_STAGE_WORDS / 32 + 1,  // one pad word per 32: threads read 16 words apart
     KHG_LUT_BITS = 12,
     KHG_LUT_SIZE = 1 << KHG_LUT_BITS,
-    KHG_NOT_CONVERGED = 1     // internal status: the host must run chained sync passes
-};
-
-// Parsed header plus derived layout, written by khg_dec_header_body.
-struct KhgDecHeader {
-    int32_t nbits[3];         // stream bits without the pad (Decompress.h:37-39)
-    int32_t k[3];             // table sizes
-    uint32_t stream_byte[3];  // byte offset of each plane's stream in the file
-    uint32_t table_byte[3];   // byte offset of each plane's table
-    int32_t lvl;
-    int32_t rows, cols;
-    int32_t ok;
-};
-
-struct KhgSubInfo {
-    uint32_t start;  // exact bit position of the first codeword starting in this subsequence
-    uint32_t count;  // symbols whose codeword starts in it
-};
-
-// Per-workgroup record kept between the decode kernels.
-struct KhgBlkInfo {
-    uint32_t arrive[2];   // where the workgroup's last thread arrived, by pass parity
-    uint32_t total;       // symbols starting in the workgroup's span
-    uint32_t out;         // raster index of the first of them (filled by the scan)
-    uint32_t pad_[4];
-};
-
-struct KhgDecWorkspace {
-    double* plane[3];   // reconstructed Y / Cb / Cr (f64)
-    uint32_t* lut;      // [3][KHG_LUT_SIZE] first-level decode tables, then the mismatch word
-    KhgBlkInfo* blk;    // per workgroup, planes concatenated
-    KhgSubInfo* sub;    // per subsequence, planes concatenated
-    uint32_t* masks;    // [subsequence][KHG_SUB_WORDS] codeword-start maps
-    KhgDecHeader* hdr;
-};
-
-struct KhgDecWorkspaceSizes {
-    size_t plane[3], lut, sub, blk, masks;
+    KHG_MAXOFF = KHG_MAX_CODE_BITS,  // start offsets 0..55
+    KHG_OFF_TEMP = 62,        // map entry not final yet: the count field holds the landing offset
+    KHG_OFF_NONE = 63         // no codeword starts from here on (the stream has ended)
 };
 
 // Decoder limit on a plane's stream: 16 bits per symbol on average.  A Huffman code built from the
@@ -77,11 +42,49 @@ struct KhgDecWorkspaceSizes {
 // stream written by Writer.h / by this library does; longer streams are rejected (KHG_ERR_RANGE).
 enum { KHG_DEC_MAX_AVG_BITS = 16 };
 
-static inline uint32_t khg_max_subs(uint64_t nsym)
+// Parsed header plus derived layout, written by khg_dec_header_body / khg_dec_tree_body.
+struct KhgDecHeader {
+    int32_t nbits[3];         // stream bits without the pad (Decompress.h:37-39)
+    int32_t k[3];             // table sizes
+    uint32_t stream_byte[3];  // byte offset of each plane's stream in the file
+    uint32_t table_byte[3];   // byte offset of each plane's table
+    int32_t maxlen[3];        // longest code of each plane
+    int32_t lvl;
+    int32_t rows, cols;
+    int32_t ok;
+};
+
+// Subsequence map entry: (arrival offset << 10) | codeword count.
+KHG_DEV uint16_t khg_map_entry(uint32_t arr, uint32_t cnt) { return (uint16_t)((arr << 10) | cnt); }
+KHG_DEV uint32_t khg_map_arr(uint16_t e) { return (uint32_t)e >> 10; }
+KHG_DEV uint32_t khg_map_cnt(uint16_t e) { return (uint32_t)e & 1023u; }
+
+// Per-workgroup record kept between the decode kernels.
+struct KhgBlkInfo {
+    uint32_t map[KHG_MAXOFF];  // start offset -> (arrival offset << 24) | codewords in the workgroup's span
+    uint32_t start_off;        // exact start offset (filled by the chain)
+    uint32_t out;              // raster index of the workgroup's first symbol (filled by the chain)
+    uint32_t pad_[6];
+};
+
+struct KhgDecWorkspace {
+    double* plane[3];   // reconstructed Y / Cb / Cr (f64)
+    uint32_t* lut;      // [3][KHG_LUT_SIZE] first-level decode tables
+    KhgBlkInfo* blk;    // per workgroup, planes concatenated
+    uint16_t* submap;   // [workgroup][KHG_MAXOFF][KHG_DEC_BLOCK] subsequence maps
+    KhgDecHeader* hdr;
+};
+
+struct KhgDecWorkspaceSizes {
+    size_t plane[3], lut, blk, submap;
+};
+
+static inline uint32_t khg_max_blocks(uint64_t nsym)
 {
     uint64_t bits = nsym * KHG_DEC_MAX_AVG_BITS;
     if (bits > 0x7FFFFFFFull) bits = 0x7FFFFFFFull;
-    return (uint32_t)((bits + KHG_SUB_BITS - 1) / KHG_SUB_BITS);
+    uint32_t b = (uint32_t)((bits + KHG_BLK_BITS - 1) / KHG_BLK_BITS);
+    return b ? b : 1;
 }
 
 struct KhgDecArgs {
@@ -98,15 +101,11 @@ struct KhgDecArgs {
     uint32_t* big_scratch;
     uint32_t* lut;         // [3][KHG_LUT_SIZE]
     KhgBlkInfo* blk;       // [nblocks]
-    uint32_t* mismatch;    // [1]
-    KhgSubInfo* sub;
-    uint32_t* masks;       // [subsequence][KHG_SUB_WORDS]
-    uint32_t sub0[3];      // first subsequence index of each plane (capacity layout)
-    uint32_t blk0[3];      // first workgroup index of each plane
+    uint16_t* submap;      // [nblocks][KHG_MAXOFF][KHG_DEC_BLOCK]
+    uint32_t blk0[3];      // first workgroup index of each plane (capacity layout)
     uint32_t nblocks;
     int16_t* sym[3];
     uint32_t n[3];         // symbols per plane
-    int pass;
 };
 
 static inline void khg_dec_workspace_sizes(int rows, int cols, KhgDecWorkspaceSizes* s)
@@ -114,12 +113,10 @@ static inline void khg_dec_workspace_sizes(int rows, int cols, KhgDecWorkspaceSi
     size_t ny = (size_t)rows * cols, nc = ny / 4;
     s->plane[0] = ny * sizeof(double);
     s->plane[1] = s->plane[2] = nc * sizeof(double);
-    size_t subs = (size_t)khg_max_subs(ny) + 2 * (size_t)khg_max_subs(nc) + 3 * KHG_DEC_BLOCK;
-    size_t blocks = subs / KHG_DEC_BLOCK + 4;
-    s->lut = (3 * (size_t)KHG_LUT_SIZE + 16) * sizeof(uint32_t);
-    s->sub = subs * sizeof(KhgSubInfo);
+    size_t blocks = (size_t)khg_max_blocks(ny) + 2 * (size_t)khg_max_blocks(nc);
+    s->lut = 3 * (size_t)KHG_LUT_SIZE * sizeof(uint32_t);
     s->blk = blocks * sizeof(KhgBlkInfo);
-    s->masks = subs * KHG_SUB_WORDS * sizeof(uint32_t);
+    s->submap = blocks * KHG_MAXOFF * KHG_DEC_BLOCK * sizeof(uint16_t);
 }
 
 KHG_DEV int32_t khg_load_le32(const uint8_t* p)
@@ -160,6 +157,7 @@ KHG_DEV void khg_dec_header_body(const KhgDecArgs& a)
                     off += 8ull * (uint64_t)k[p];
                     h->nbits[p] = len[p] - pad[p];
                     h->k[p] = k[p];
+                    h->maxlen[p] = 0;
                     // a single-entry table has the empty code: its stream must be empty (Huffman.h:57-68)
                     if (k[p] == 1 && h->nbits[p] != 0) ok = 0;
                     if (k[p] > 1 && (uint64_t)h->nbits[p] > (uint64_t)a.n[p] * KHG_DEC_MAX_AVG_BITS) {
@@ -171,7 +169,6 @@ KHG_DEV void khg_dec_header_body(const KhgDecArgs& a)
             }
             h->ok = ok;
             if (!ok) khg_set_status(&a.res->status, -3);
-            a.mismatch[0] = 0;
         }
     }
 }
@@ -179,15 +176,27 @@ KHG_DEV void khg_dec_header_body(const KhgDecArgs& a)
 struct KhgDecTreeSmem {
     alignas(16) uint32_t w[6 * KHG_TREE_LDS_K + 8];
     int32_t root;
+    int maxlen;
 };
 
+// Depth of a leaf = length of its code (Huffman.h:57-68).
+KHG_DEV int khg_leaf_depth(const uint32_t* parent, int leaf, int root)
+{
+    int len = 0, node = leaf;
+    while (node != root) {
+        node = (int)(parent[node] & 0x7FFFFFFFu);
+        ++len;
+    }
+    return len;
+}
+
 // bid = colour component.  Rebuilds the tree from the stored table with the encoder's own
-// construction (Decompress.h:45-47) and fills the first-level decode table.
+// construction (Decompress.h:45-47), finds the longest code and fills the first-level decode table.
 // LUT entry: bit 31 set = leaf reached within KHG_LUT_BITS bits: bits 16..23 code length,
 // bits 0..15 symbol (int16); otherwise the entry is the node reached after KHG_LUT_BITS bits.
 KHG_DEV void khg_dec_tree_body(const KhgDecArgs& a, int bid, KhgDecTreeSmem& sh)
 {
-    const KhgDecHeader* h = a.hdr;
+    KhgDecHeader* h = a.hdr;
     if (!h->ok) return;
     const int k = h->k[bid];
     int32_t* tcnt = a.tab_cnt + (size_t)bid * KHG_NBINS;
@@ -205,32 +214,57 @@ KHG_DEV void khg_dec_tree_body(const KhgDecArgs& a, int bid, KhgDecTreeSmem& sh)
             tsym[i] = s;
             if (s < -32768 || s > 32767) khg_set_status(&a.res->status, -4);
         }
+        if (tid == 0) sh.maxlen = 0;
     }
     KHG_BARRIER();
     if (k <= KHG_TREE_LDS_K) {  // separate copies: LDS vs global address space of the heap arrays
+        uint32_t* parent = sh.w + 4 * KHG_TREE_LDS_K + 4;
         KHG_FOR_THREADS(256)
         {
             if (tid == 0) {
-                sh.root = khg_tree_build(tcnt, k, (uint64_t*)sh.w + 1, sh.w + 2 * KHG_TREE_LDS_K + 4,
-                                         sh.w + 4 * KHG_TREE_LDS_K + 4, left, right);
+                sh.root = khg_tree_build(tcnt, k, (uint64_t*)sh.w + 1, sh.w + 2 * KHG_TREE_LDS_K + 4, parent, left, right);
                 a.tree_root[bid] = sh.root;
             }
         }
+        KHG_BARRIER();
+        KHG_FOR_THREADS(256)
+        {
+            int m = 0;
+            for (int i = tid; i < k; i += 256) {
+                int d = khg_leaf_depth(parent, i, sh.root);
+                m = d > m ? d : m;
+            }
+            if (m) khg_atomic_max_i(&sh.maxlen, m);
+        }
     } else {
         uint32_t* g = a.big_scratch + (size_t)bid * 10 * KHG_NBINS;
+        uint32_t* parent = g + 4 * KHG_NBINS + 4;
         KHG_FOR_THREADS(256)
         {
             if (tid == 0) {
-                sh.root = khg_tree_build(tcnt, k, (uint64_t*)g + 1, g + 2 * KHG_NBINS + 4, g + 4 * KHG_NBINS + 4, left,
-                                         right);
+                sh.root = khg_tree_build(tcnt, k, (uint64_t*)g + 1, g + 2 * KHG_NBINS + 4, parent, left, right);
                 a.tree_root[bid] = sh.root;
             }
+        }
+        KHG_BARRIER();
+        KHG_FOR_THREADS(256)
+        {
+            int m = 0;
+            for (int i = tid; i < k; i += 256) {
+                int d = khg_leaf_depth(parent, i, sh.root);
+                m = d > m ? d : m;
+            }
+            if (m) khg_atomic_max_i(&sh.maxlen, m);
         }
     }
     KHG_BARRIER();
     KHG_FOR_THREADS(256)
     {
         const int root = sh.root;
+        if (tid == 0) {
+            h->maxlen[bid] = sh.maxlen;
+            if (sh.maxlen > KHG_MAX_CODE_BITS) khg_set_status(&a.res->status, -4);
+        }
         for (int v = tid; v < KHG_LUT_SIZE; v += 256) {
             int node = root, d = 0;
             uint32_t e;
@@ -249,32 +283,16 @@ KHG_DEV void khg_dec_tree_body(const KhgDecArgs& a, int bid, KhgDecTreeSmem& sh)
     }
 }
 
-// --------------------------------------------------------------- bit readers
+// --------------------------------------------------------------- bit reader
 
-// Stream bits straight from the file in global memory (used where only a few codewords are read).
-struct KhgBitsG {
-    const uint32_t* words;  // file as aligned 32-bit words
-    uint64_t base;          // bit offset of the plane's stream in the file
-    uint32_t nbits;         // stream length in bits
-    uint32_t nwords;        // readable words
-    // 32 stream bits starting at stream position pos, first bit in bit 31 (zeros past the end)
-    KHG_DEV uint32_t peek32(uint32_t pos) const
-    {
-        uint64_t g = base + pos;
-        uint32_t w = (uint32_t)(g >> 5), s = (uint32_t)(g & 31);
-        uint32_t w0 = w < nwords ? khg_bswap32(words[w]) : 0;
-        uint32_t w1 = w + 1 < nwords ? khg_bswap32(words[w + 1]) : 0;
-        return s ? (w0 << s) | (w1 >> (32 - s)) : w0;
-    }
-};
-
-// The same view over a workgroup's span staged in LDS as byte-swapped words.
 KHG_DEV uint32_t khg_stage_slot(uint32_t w) { return w + (w >> 5); }
 
+// A workgroup's span of the stream staged in LDS as byte-swapped words at khg_stage_slot() positions.
 struct KhgBitsL {
-    const uint32_t* stage;  // KHG_STAGE_WORDS words at khg_stage_slot() positions
-    uint32_t bias;          // stream position of bit 31 of stage[0] (may be "negative": wraps, used modulo 2^32)
-    uint32_t nbits;
+    const uint32_t* stage;
+    uint32_t bias;   // stream position of bit 31 of stage word 0 (modulo 2^32)
+    uint32_t nbits;  // stream length in bits
+    // 32 stream bits starting at stream position pos, first bit in bit 31
     KHG_DEV uint32_t peek32(uint32_t pos) const
     {
         uint32_t l = pos - bias;
@@ -290,19 +308,8 @@ KHG_DEV int khg_block_plane(const KhgDecArgs& a, uint32_t blk)
     return blk >= a.blk0[2] ? 2 : blk >= a.blk0[1] ? 1 : 0;
 }
 
-KHG_DEV KhgBitsG khg_plane_bits(const KhgDecArgs& a, int p)
-{
-    KhgBitsG b;
-    b.words = (const uint32_t*)a.comp;
-    b.base = 8ull * a.hdr->stream_byte[p];
-    b.nbits = (uint32_t)a.hdr->nbits[p];
-    b.nwords = (uint32_t)(a.len >> 2);
-    return b;
-}
-
 // Decode one codeword at pos.  Returns its length (0 = the stream ends inside it) and symbol.
-template <class Bits>
-KHG_DEV uint32_t khg_decode_one(const Bits& b, const uint32_t* lut, const int32_t* left, const int32_t* right,
+KHG_DEV uint32_t khg_decode_one(const KhgBitsL& b, const uint32_t* lut, const int32_t* left, const int32_t* right,
                                 const int32_t* tsym, uint32_t pos, int* sym)
 {
     uint32_t window = b.peek32(pos);
@@ -327,315 +334,232 @@ KHG_DEV uint32_t khg_decode_one(const Bits& b, const uint32_t* lut, const int32_
     return len;
 }
 
-// Codeword-start bitmap of one subsequence: word w of thread t lives at mask[w * stride + t * tstride];
-// position r (0..511) is bit 31 - (r & 31) of word r >> 5.
-struct KhgMaskRef {
-    uint32_t* m;
-    uint32_t wstride;
-    KHG_DEV uint32_t& word(uint32_t w) const { return m[w * wstride]; }
-};
-
-// Decode from `start` (inside the subsequence beginning at sub_begin) until the first codeword
-// boundary at or after `end`.  Codeword starts are recorded in `mask`.  With has_old, `mask`
-// holds the starts of an earlier run of the same subsequence: landing on one of them means the
-// two runs coincide from there on, so the earlier arrival (*arrive on entry) stands and the
-// earlier starts at and after that point are kept and counted.  Returns the arrival position
-// (0xFFFFFFFF: the stream ends inside a codeword) and the number of codewords started.
-template <class Bits>
-KHG_DEV void khg_decode_span(const Bits& b, const uint32_t* lut, const int32_t* left, const int32_t* right,
-                             const int32_t* tsym, uint32_t sub_begin, uint32_t start, uint32_t end, bool has_old,
-                             const KhgMaskRef& mask, uint32_t* arrive, uint32_t* count)
-{
-    uint32_t pos = start, n = 0;
-    uint32_t widx = (start - sub_begin) >> 5;
-    for (uint32_t w = 0; w < widx; ++w) mask.word(w) = 0;
-    uint32_t oldw = has_old ? mask.word(widx) : 0, cur = 0;
-    bool exhausted = false;
-    while (pos < end) {
-        uint32_t rel = pos - sub_begin, w = rel >> 5;
-        while (widx < w) {
-            mask.word(widx) = cur;
-            ++widx;
-            cur = 0;
-            oldw = has_old ? mask.word(widx) : 0;
-        }
-        uint32_t bit = 0x80000000u >> (rel & 31);
-        if (oldw & bit) {
-            // rejoined the earlier run: keep its starts from here on
-            uint32_t ge = bit | (bit - 1);
-            uint32_t rest = (uint32_t)__builtin_popcount(oldw & ge);
-            mask.word(widx) = cur | (oldw & ge);
-            for (uint32_t w2 = widx + 1; w2 < KHG_SUB_WORDS; ++w2) rest += (uint32_t)__builtin_popcount(mask.word(w2));
-            *count = n + rest;
-            return;  // *arrive unchanged
-        }
-        int s;
-        uint32_t len = khg_decode_one(b, lut, left, right, tsym, pos, &s);
-        if (len == 0) {
-            exhausted = true;
-            break;
-        }
-        cur |= bit;
-        pos += len;
-        ++n;
-    }
-    mask.word(widx) = cur;
-    for (uint32_t w2 = widx + 1; w2 < KHG_SUB_WORDS; ++w2) mask.word(w2) = 0;
-    *arrive = exhausted ? 0xFFFFFFFFu : pos;
-    *count = n;
-}
-
 struct KhgDecSmem {
     uint32_t lut[KHG_LUT_SIZE];
     uint32_t stage[KHG_STAGE_LDS];
     uint32_t mask[KHG_SUB_WORDS * KHG_DEC_BLOCK];  // word-major: thread t's word w at [w * 256 + t]
-    uint32_t arrive[KHG_DEC_BLOCK];
-    uint32_t count[KHG_DEC_BLOCK];
-    uint32_t used[KHG_DEC_BLOCK];
+    uint16_t map[KHG_MAXOFF * KHG_DEC_BLOCK];      // offset-major: thread t's entry for offset o at [o * 256 + t]
     uint32_t grp[16];
-    uint32_t changed[2];
-    uint32_t blk_start;
 };
 
 // Stage the LUT and the workgroup's span of the stream (byte-swapped words) in LDS.
 KHG_DEV KhgBitsL khg_dec_stage(const KhgDecArgs& a, int p, uint32_t blk_begin, KhgDecSmem& sh)
 {
-    const KhgBitsG g = khg_plane_bits(a, p);
+    const uint32_t* words = (const uint32_t*)a.comp;
+    const uint32_t nwords = (uint32_t)(a.len >> 2);
     const uint32_t* glut = a.lut + (size_t)p * KHG_LUT_SIZE;
-    const uint64_t gbit = g.base + blk_begin;
+    const uint64_t gbit = 8ull * a.hdr->stream_byte[p] + blk_begin;
     const uint32_t w0 = (uint32_t)(gbit >> 5);
     KHG_FOR_THREADS(256)
     {
         for (int i = tid; i < KHG_LUT_SIZE; i += 256) sh.lut[i] = glut[i];
         for (uint32_t i = (uint32_t)tid; i < KHG_STAGE_WORDS; i += 256) {
             uint32_t w = w0 + i;
-            sh.stage[khg_stage_slot(i)] = w < g.nwords ? khg_bswap32(g.words[w]) : 0;
+            sh.stage[khg_stage_slot(i)] = w < nwords ? khg_bswap32(words[w]) : 0;
         }
     }
     KhgBitsL l;
     l.stage = sh.stage;
     l.bias = blk_begin - (uint32_t)(gbit & 31);
-    l.nbits = g.nbits;
+    l.nbits = (uint32_t)a.hdr->nbits[p];
     return l;
 }
 
-// One workgroup = 256 consecutive subsequences of one plane.
-// pass 0: the workgroup's first thread starts at the nominal position (exact only for the plane's
-// first workgroup).  pass > 0 (chained passes, only when the fix kernel reported a mismatch): it
-// starts where the previous workgroup arrived in the previous pass, and a changed arrival is counted.
-KHG_DEV void khg_dec_sync_body(const KhgDecArgs& a, uint32_t blk, KhgDecSmem& sh)
+// One workgroup = 256 consecutive subsequences of one plane: subsequence maps and their composition.
+KHG_DEV void khg_dec_map_body(const KhgDecArgs& a, uint32_t blk, KhgDecSmem& sh)
 {
     if (!a.hdr->ok) return;
     const int p = khg_block_plane(a, blk);
     const uint32_t nbits = (uint32_t)a.hdr->nbits[p];
     const uint32_t lb = blk - a.blk0[p];  // workgroup index inside the plane
     const uint32_t blk_begin = lb * KHG_BLK_BITS;
-    if (blk_begin >= nbits && lb != 0) return;  // beyond the stream (workgroup 0 still records zeros)
+    if (blk_begin >= nbits) return;
+    const uint32_t M = (uint32_t)a.hdr->maxlen[p];
+    if (M == 0 || M > KHG_MAXOFF) return;  // flagged by the tree kernel
     const int32_t* left = a.tree_left + (size_t)p * 2 * KHG_NBINS;
     const int32_t* right = a.tree_right + (size_t)p * 2 * KHG_NBINS;
     const int32_t* tsym = a.tab_sym + (size_t)p * KHG_NBINS;
-    KhgBlkInfo* bi = a.blk + blk;
     const KhgBitsL bits = khg_dec_stage(a, p, blk_begin, sh);
+    KHG_BARRIER();
 
     KHG_FOR_THREADS(256)
     {
-        if (tid == 0) {
-            uint32_t s = blk_begin;
-            if (lb == 0) s = 0;
-            else if (a.pass > 0) s = a.blk[blk - 1].arrive[(a.pass + 1) & 1];
-            sh.blk_start = s;
-            sh.changed[0] = 0;
-            sh.changed[1] = 0;
-        }
-        sh.used[tid] = 0xFFFFFFFEu;  // "no start decoded yet"
-        sh.arrive[tid] = blk_begin + ((uint32_t)tid + 1) * KHG_SUB_BITS;  // nominal arrival for the first round
-        sh.count[tid] = 0;
-    }
-    KHG_BARRIER();
-    // Every round, a thread whose predecessor's arrival differs from the start it last decoded
-    // from runs again.  An exact start propagates at least one thread per round.
-    for (int round = 0; round <= KHG_DEC_BLOCK; ++round) {
-        uint32_t mystart[KHG_NSLOT(256)];
-        KHG_FOR_THREADS(256)
-        {
-            mystart[KHG_SLOT] = tid == 0 ? sh.blk_start : sh.arrive[tid - 1];
-        }
-        KHG_BARRIER();
-        KHG_FOR_THREADS(256)
-        {
-            const uint32_t s = mystart[KHG_SLOT];
-            const uint32_t sub_begin = blk_begin + (uint32_t)tid * KHG_SUB_BITS;
-            const uint32_t end = sub_begin + KHG_SUB_BITS;
-            if (s != sh.used[tid]) {
-                const bool has_old = sh.used[tid] != 0xFFFFFFFEu && sh.used[tid] < nbits && sh.used[tid] < end;
-                uint32_t cnt = 0, arr = sh.arrive[tid];
-                KhgMaskRef mr = {&sh.mask[tid], KHG_DEC_BLOCK};
-                if (s >= nbits || s >= end) {
-                    arr = s;  // nothing starts in this subsequence (s >= end cannot happen: 512 > longest code)
-                    for (uint32_t w = 0; w < KHG_SUB_WORDS; ++w) mr.word(w) = 0;
-                } else {
-                    khg_decode_span(bits, sh.lut, left, right, tsym, sub_begin, s, end < nbits ? end : nbits, has_old,
-                                    mr, &arr, &cnt);
-                }
-                sh.used[tid] = s;
-                sh.arrive[tid] = arr;
-                sh.count[tid] = cnt;
-                sh.changed[round & 1] = 1;
+        const uint32_t sub_begin = blk_begin + (uint32_t)tid * KHG_SUB_BITS;
+        const uint32_t end = sub_begin + KHG_SUB_BITS < nbits ? sub_begin + KHG_SUB_BITS : nbits;
+        uint16_t* map = &sh.map[tid];
+        uint32_t* mask = &sh.mask[tid];
+        // 1. first codeword from every start offset: where does it land?
+        for (uint32_t o = 0; o < M; ++o) {
+            uint32_t pos = sub_begin + o;
+            uint16_t e = khg_map_entry(KHG_OFF_NONE, 0);
+            if (pos < end) {
+                int s;
+                uint32_t len = khg_decode_one(bits, sh.lut, left, right, tsym, pos, &s);
+                if (len) e = khg_map_entry(KHG_OFF_TEMP, o + len);  // landing offset < 2 * 56
             }
+            map[o * KHG_DEC_BLOCK] = e;
         }
-        KHG_BARRIER();
-        const bool any = sh.changed[round & 1] != 0;
-#ifdef KHG_SIM_STATS
-        if (any) bi->pad_[0] = (uint32_t)round + 1;
-#endif
-        KHG_FOR_THREADS(256)
-        {
-            if (tid == 0) sh.changed[(round + 1) & 1] = 0;
-        }
-        KHG_BARRIER();
-        if (!any) break;
-    }
-    KHG_FOR_THREADS(256)
-    {
-        KhgSubInfo si;
-        si.start = sh.used[tid];
-        si.count = sh.count[tid];
-        a.sub[a.sub0[p] + lb * KHG_DEC_BLOCK + tid] = si;
-        if (tid < 16) {
-            uint32_t t = 0;
-            for (int i = 0; i < 16; ++i) t += sh.count[tid * 16 + i];
-            sh.grp[tid] = t;
-        }
-        uint32_t* gm = a.masks + ((size_t)a.sub0[p] + (size_t)lb * KHG_DEC_BLOCK + tid) * KHG_SUB_WORDS;
-        for (int w = 0; w < KHG_SUB_WORDS; ++w) gm[w] = sh.mask[w * KHG_DEC_BLOCK + tid];
-    }
-    KHG_BARRIER();
-    KHG_FOR_THREADS(256)
-    {
-        if (tid == 0) {
-            uint32_t t = 0;
-            for (int i = 0; i < 16; ++i) t += sh.grp[i];
-            bi->total = t;
-            uint32_t arr = sh.arrive[KHG_DEC_BLOCK - 1];
-            if (a.pass > 0 && bi->arrive[(a.pass + 1) & 1] != arr) khg_atomic_add(a.mismatch, 1u);
-            bi->arrive[a.pass & 1] = arr;
-        }
-    }
-}
-
-// After sync pass 0: one thread per workgroup re-runs the workgroup's leading subsequences from
-// where the previous workgroup arrived, subsequence after subsequence, until the run rejoins
-// the speculative one (normally within a few codewords of the first subsequence).  If it walks
-// through the whole workgroup and arrives somewhere else, the speculation failed for the next
-// workgroup too and a mismatch is recorded.
-KHG_DEV void khg_dec_fix_body(const KhgDecArgs& a, uint32_t bid)
-{
-    if (!a.hdr->ok) return;
-    KHG_FOR_THREADS(256)
-    {
-        const uint32_t blk = bid * 256 + (uint32_t)tid;
-        if (blk < a.nblocks) {
-            const int p = khg_block_plane(a, blk);
-            const uint32_t lb = blk - a.blk0[p];
-            const KhgBitsG bits = khg_plane_bits(a, p);
-            const uint32_t blk_begin = lb * KHG_BLK_BITS;
-            if (lb != 0 && blk_begin < bits.nbits) {
-                KhgBlkInfo* bi = a.blk + blk;
-                KhgSubInfo* sub = a.sub + a.sub0[p] + (size_t)lb * KHG_DEC_BLOCK;
-                uint32_t* masks = a.masks + ((size_t)a.sub0[p] + (size_t)lb * KHG_DEC_BLOCK) * KHG_SUB_WORDS;
-                uint32_t s = a.blk[blk - 1].arrive[0];
-                uint32_t total = bi->total;
-                bool joined = false;
-                for (uint32_t t = 0; t < KHG_DEC_BLOCK; ++t) {
-                    if (s == sub[t].start) {
+        // 2. offsets whose first codeword leaves the first M bits run on; the first run records
+        //    its codeword starts, later runs stop when they land on one of them
+        bool have_main = false;
+        uint32_t main_arr = KHG_OFF_NONE;
+        for (uint32_t oo = M; oo-- > 0;) {
+            const uint16_t e0 = map[oo * KHG_DEC_BLOCK];
+            if (khg_map_arr(e0) != KHG_OFF_TEMP || khg_map_cnt(e0) < M) continue;
+            uint32_t pos = sub_begin + khg_map_cnt(e0), n = 1;
+            bool joined = false, dead = false;
+            const bool is_main = !have_main;
+            if (is_main) {
+                for (uint32_t w = 0; w < KHG_SUB_WORDS; ++w) mask[w * KHG_DEC_BLOCK] = 0;
+                uint32_t widx = 0xFFFFFFFFu, cur = 0;
+                while (pos < end) {
+                    uint32_t rel = pos - sub_begin, w = rel >> 5;
+                    if (w != widx) {
+                        if (widx != 0xFFFFFFFFu) mask[widx * KHG_DEC_BLOCK] = cur;
+                        widx = w;
+                        cur = 0;
+                    }
+                    int s;
+                    uint32_t len = khg_decode_one(bits, sh.lut, left, right, tsym, pos, &s);
+                    if (len == 0) {
+                        dead = true;
+                        break;
+                    }
+                    cur |= 0x80000000u >> (rel & 31);
+                    pos += len;
+                    ++n;
+                }
+                if (widx != 0xFFFFFFFFu) mask[widx * KHG_DEC_BLOCK] = cur;
+                have_main = true;
+            } else {
+                uint32_t widx = 0xFFFFFFFFu, mw = 0;
+                while (pos < end) {
+                    uint32_t rel = pos - sub_begin, w = rel >> 5;
+                    if (w != widx) {
+                        widx = w;
+                        mw = mask[w * KHG_DEC_BLOCK];
+                    }
+                    uint32_t bit = 0x80000000u >> (rel & 31);
+                    if (mw & bit) {  // landed on a codeword start of the first run: identical from here on
+                        uint32_t rest = (uint32_t)__builtin_popcount(mw & (bit | (bit - 1)));
+                        for (uint32_t w2 = w + 1; w2 < KHG_SUB_WORDS; ++w2)
+                            rest += (uint32_t)__builtin_popcount(mask[w2 * KHG_DEC_BLOCK]);
+                        n += rest;
                         joined = true;
                         break;
                     }
-                    const uint32_t sub_begin = blk_begin + t * KHG_SUB_BITS, end = sub_begin + KHG_SUB_BITS;
-                    const uint32_t old_start = sub[t].start, old_cnt = sub[t].count;
-                    const uint32_t old_arr = t + 1 < KHG_DEC_BLOCK ? sub[t + 1].start : bi->arrive[0];
-                    uint32_t arr = old_arr, cnt = 0;
-                    KhgMaskRef mr = {masks + (size_t)t * KHG_SUB_WORDS, 1};
-                    if (s >= bits.nbits || s >= end) {
-                        arr = s;
-                    } else {
-                        const bool has_old = old_start < bits.nbits && old_start < end;
-                        khg_decode_span(bits, a.lut + (size_t)p * KHG_LUT_SIZE, a.tree_left + (size_t)p * 2 * KHG_NBINS,
-                                        a.tree_right + (size_t)p * 2 * KHG_NBINS, a.tab_sym + (size_t)p * KHG_NBINS,
-                                        sub_begin, s, end < bits.nbits ? end : bits.nbits, has_old, mr, &arr, &cnt);
-                    }
-                    sub[t].start = s;
-                    sub[t].count = cnt;
-                    total = total - old_cnt + cnt;
-                    if (arr == old_arr) {
-                        joined = true;
+                    int s;
+                    uint32_t len = khg_decode_one(bits, sh.lut, left, right, tsym, pos, &s);
+                    if (len == 0) {
+                        dead = true;
                         break;
                     }
-                    s = arr;
+                    pos += len;
+                    ++n;
                 }
-                bi->total = total;
-                if (!joined) khg_atomic_add(a.mismatch, 1u);
             }
+            uint32_t arr;
+            if (joined) arr = main_arr;
+            else if (dead || pos >= nbits) arr = KHG_OFF_NONE;
+            else arr = pos - (sub_begin + KHG_SUB_BITS);  // pos >= sub_begin + 512, overshoot < M
+            if (is_main) main_arr = arr;
+            map[oo * KHG_DEC_BLOCK] = khg_map_entry(arr, n);
         }
+        // 3. the other offsets reuse the entry of the offset their first codeword lands on
+        for (uint32_t oo = M; oo-- > 0;) {
+            const uint16_t e0 = map[oo * KHG_DEC_BLOCK];
+            if (khg_map_arr(e0) != KHG_OFF_TEMP) continue;
+            const uint16_t r = map[khg_map_cnt(e0) * KHG_DEC_BLOCK];  // landing offset > oo: already final
+            map[oo * KHG_DEC_BLOCK] = khg_map_entry(khg_map_arr(r), khg_map_cnt(r) + 1);
+        }
+    }
+    KHG_BARRIER();
+    KHG_FOR_THREADS(256)
+    {
+        // compose the 256 subsequence maps: one lane per start offset of the workgroup
+        if ((uint32_t)tid < M) {
+            uint32_t off = (uint32_t)tid, tot = 0;
+            for (uint32_t t = 0; t < KHG_DEC_BLOCK && off != KHG_OFF_NONE; ++t) {
+                uint16_t e = sh.map[off * KHG_DEC_BLOCK + t];
+                tot += khg_map_cnt(e);
+                off = khg_map_arr(e);
+            }
+            a.blk[blk].map[tid] = (off << 24) | tot;
+        }
+        uint16_t* gm = a.submap + (size_t)blk * KHG_MAXOFF * KHG_DEC_BLOCK;
+        for (uint32_t o = 0; o < M; ++o) gm[o * KHG_DEC_BLOCK + tid] = sh.map[o * KHG_DEC_BLOCK + tid];
     }
 }
 
-struct KhgDecScanSmem {
-    uint64_t psum[1024];
+struct KhgDecChainSmem {
+    uint32_t map[KHG_DEC_BLOCK * KHG_MAXOFF];
+    uint32_t total;
 };
 
-// Single workgroup, 1024 threads: raster index of every workgroup's first symbol; zero-fills raster
-// cells past the decoded symbols (Huffman.h:35: the matrix starts zero-initialised).
-KHG_DEV void khg_dec_scan_body(const KhgDecArgs& a, KhgDecScanSmem& sh)
+// bid = colour component.  Thread 0 walks the workgroup maps from bit 0; the others stage the maps
+// in LDS and afterwards zero-fill raster cells past the decoded symbols (Huffman.h:35: the matrix
+// starts zero-initialised).
+KHG_DEV void khg_dec_chain_body(const KhgDecArgs& a, int bid, KhgDecChainSmem& sh)
 {
     if (!a.hdr->ok) return;
-    KHG_FOR_THREADS(1024)
+    const int p = bid;
+    const uint32_t nbits = (uint32_t)a.hdr->nbits[p];
+    const uint32_t nb = (nbits + KHG_BLK_BITS - 1) / KHG_BLK_BITS;  // active workgroups of this plane
+    KhgBlkInfo* blk = a.blk + a.blk0[p];
+    uint32_t off_c[KHG_NSLOT(256)], out_c[KHG_NSLOT(256)];
+    KHG_FOR_THREADS(256)
     {
-        if (tid == 0 && a.mismatch[0] != 0) khg_set_status(&a.res->status, KHG_NOT_CONVERGED);
+        off_c[KHG_SLOT] = 0;
+        out_c[KHG_SLOT] = 0;
     }
-    for (int p = 0; p < 3; ++p) {
-        const uint32_t nbits = (uint32_t)a.hdr->nbits[p];
-        const uint32_t nb = (nbits + KHG_BLK_BITS - 1) / KHG_BLK_BITS;  // active workgroups of this plane
-        const uint32_t per = (nb + 1023) / 1024;
-        KhgBlkInfo* blk = a.blk + a.blk0[p];
-        KHG_FOR_THREADS(1024)
+    for (uint32_t t0 = 0; t0 < nb; t0 += KHG_DEC_BLOCK) {
+        const uint32_t nt = nb - t0 < KHG_DEC_BLOCK ? nb - t0 : KHG_DEC_BLOCK;
+        KHG_FOR_THREADS(256)
         {
-            uint64_t s = 0;
-            uint32_t c0 = (uint32_t)tid * per, c1 = c0 + per < nb ? c0 + per : nb;
-            for (uint32_t c = c0; c < c1; ++c) s += blk[c].total;
-            sh.psum[tid] = s;
+            for (uint32_t i = (uint32_t)tid; i < nt * KHG_MAXOFF; i += 256)
+                sh.map[i] = blk[t0 + i / KHG_MAXOFF].map[i % KHG_MAXOFF];
         }
         KHG_BARRIER();
-        KHG_FOR_THREADS(1024)
+        KHG_FOR_THREADS(256)
         {
             if (tid == 0) {
-                uint64_t run = 0;
-                for (int t = 0; t < 1024; ++t) {
-                    uint64_t v = sh.psum[t];
-                    sh.psum[t] = run;
-                    run += v;
+                uint32_t off = off_c[KHG_SLOT], out = out_c[KHG_SLOT];
+                for (uint32_t b = 0; b < nt; ++b) {
+                    blk[t0 + b].start_off = off;
+                    blk[t0 + b].out = out;
+                    if (off != KHG_OFF_NONE) {
+                        uint32_t e = sh.map[b * KHG_MAXOFF + off];
+                        uint32_t tot = e & 0xFFFFFFu;
+                        out = out + tot < out ? 0xFFFFFFFFu : out + tot;
+                        off = e >> 24;
+                    }
                 }
-                if (run > a.n[p]) khg_set_status(&a.res->status, -3);  // the reference would write out of bounds
-                a.res->bits[p] = (int32_t)(run > a.n[p] ? a.n[p] : run);  // symbols decoded
+                off_c[KHG_SLOT] = off;
+                out_c[KHG_SLOT] = out;
             }
         }
         KHG_BARRIER();
-        KHG_FOR_THREADS(1024)
-        {
-            uint32_t c0 = (uint32_t)tid * per, c1 = c0 + per < nb ? c0 + per : nb;
-            uint64_t run = sh.psum[tid];
-            for (uint32_t c = c0; c < c1; ++c) {
-                blk[c].out = (uint32_t)(run > 0xFFFFFFFFull ? 0xFFFFFFFFull : run);
-                run += blk[c].total;
+    }
+    KHG_FOR_THREADS(256)
+    {
+        if (tid == 0) {
+            uint32_t out = out_c[KHG_SLOT];
+            if (out > a.n[p]) {
+                khg_set_status(&a.res->status, -3);  // the reference would write out of bounds
+                out = a.n[p];
             }
-            uint32_t decoded = (uint32_t)a.res->bits[p];
-            for (uint32_t i = decoded + (uint32_t)tid; i < a.n[p]; i += 1024) a.sym[p][i] = 0;
+            a.res->bits[p] = (int32_t)out;  // symbols decoded
+            sh.total = out;
         }
-        KHG_BARRIER();
+    }
+    KHG_BARRIER();
+    KHG_FOR_THREADS(256)
+    {
+        for (uint32_t i = sh.total + (uint32_t)tid; i < a.n[p]; i += 256) a.sym[p][i] = 0;
     }
 }
 
-// One workgroup = 256 subsequences: decode each from its exact start and store the symbols.
+// One workgroup = 256 subsequences: resolve every exact start, then decode and store the symbols.
 KHG_DEV void khg_dec_write_body(const KhgDecArgs& a, uint32_t blk, KhgDecSmem& sh)
 {
     if (!a.hdr->ok || a.res->status != 0) return;
@@ -644,15 +568,36 @@ KHG_DEV void khg_dec_write_body(const KhgDecArgs& a, uint32_t blk, KhgDecSmem& s
     const uint32_t lb = blk - a.blk0[p];
     const uint32_t blk_begin = lb * KHG_BLK_BITS;
     if (blk_begin >= nbits) return;
+    const uint32_t M = (uint32_t)a.hdr->maxlen[p];
+    if (M == 0 || M > KHG_MAXOFF) return;
     const int32_t* left = a.tree_left + (size_t)p * 2 * KHG_NBINS;
     const int32_t* right = a.tree_right + (size_t)p * 2 * KHG_NBINS;
     const int32_t* tsym = a.tab_sym + (size_t)p * KHG_NBINS;
-    const KhgSubInfo* sub = a.sub + a.sub0[p] + (size_t)lb * KHG_DEC_BLOCK;
+    uint32_t* s_off = sh.mask;                       // the codeword-start maps are not needed here:
+    uint32_t* s_cnt = sh.mask + KHG_DEC_BLOCK;       // their space holds start offset, count and
+    uint32_t* s_pre = sh.mask + 2 * KHG_DEC_BLOCK;   // count prefix of every subsequence
     const KhgBitsL bits = khg_dec_stage(a, p, blk_begin, sh);
     KHG_FOR_THREADS(256)
     {
-        sh.used[tid] = sub[tid].start;
-        sh.count[tid] = sub[tid].count;
+        const uint16_t* gm = a.submap + (size_t)blk * KHG_MAXOFF * KHG_DEC_BLOCK;
+        for (uint32_t o = 0; o < M; ++o) sh.map[o * KHG_DEC_BLOCK + tid] = gm[o * KHG_DEC_BLOCK + tid];
+    }
+    KHG_BARRIER();
+    KHG_FOR_THREADS(256)
+    {
+        if (tid == 0) {
+            uint32_t off = a.blk[blk].start_off;
+            for (uint32_t t = 0; t < KHG_DEC_BLOCK; ++t) {
+                s_off[t] = off;
+                uint32_t c = 0;
+                if (off != KHG_OFF_NONE) {
+                    uint16_t e = sh.map[off * KHG_DEC_BLOCK + t];
+                    c = khg_map_cnt(e);
+                    off = khg_map_arr(e);
+                }
+                s_cnt[t] = c;
+            }
+        }
     }
     KHG_BARRIER();
     KHG_FOR_THREADS(256)
@@ -660,8 +605,8 @@ KHG_DEV void khg_dec_write_body(const KhgDecArgs& a, uint32_t blk, KhgDecSmem& s
         if (tid < 16) {  // exclusive scan of the counts inside each group of 16 threads
             uint32_t run = 0;
             for (int i = 0; i < 16; ++i) {
-                sh.arrive[tid * 16 + i] = run;
-                run += sh.count[tid * 16 + i];
+                s_pre[tid * 16 + i] = run;
+                run += s_cnt[tid * 16 + i];
             }
             sh.grp[tid] = run;
         }
@@ -669,17 +614,19 @@ KHG_DEV void khg_dec_write_body(const KhgDecArgs& a, uint32_t blk, KhgDecSmem& s
     KHG_BARRIER();
     KHG_FOR_THREADS(256)
     {
-        uint32_t o = a.blk[blk].out + sh.arrive[tid];
-        for (int g = 0; g < (tid >> 4); ++g) o += sh.grp[g];
-        uint32_t pos = sh.used[tid];
-        const uint32_t cnt = sh.count[tid];
-        int16_t* q = a.sym[p];
-        for (uint32_t i = 0; i < cnt; ++i) {
-            int s;
-            uint32_t len = khg_decode_one(bits, sh.lut, left, right, tsym, pos, &s);
-            if (len == 0) break;
-            if (o + i < a.n[p]) q[o + i] = (int16_t)s;
-            pos += len;
+        const uint32_t off = s_off[tid], cnt = s_cnt[tid];
+        if (off != KHG_OFF_NONE && cnt) {
+            uint32_t o = a.blk[blk].out + s_pre[tid];
+            for (int g = 0; g < (tid >> 4); ++g) o += sh.grp[g];
+            uint32_t pos = blk_begin + (uint32_t)tid * KHG_SUB_BITS + off;
+            int16_t* q = a.sym[p];
+            for (uint32_t i = 0; i < cnt; ++i) {
+                int s;
+                uint32_t len = khg_decode_one(bits, sh.lut, left, right, tsym, pos, &s);
+                if (len == 0) break;
+                if (o + i < a.n[p]) q[o + i] = (int16_t)s;
+                pos += len;
+            }
         }
     }
 }

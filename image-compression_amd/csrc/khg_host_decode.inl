@@ -33,41 +33,6 @@ extern "C" int khg_peek(const uint8_t* comp, size_t len, khg_header* hdr)
     return KHG_OK;
 }
 
-static void khg_launch_sync_pass(const KhgDecArgs& d, int pass, hipStream_t st)
-{
-    KhgDecArgs a = d;
-    a.pass = pass;
-    hipLaunchKernelGGL(khg_dec_sync_kernel, dim3(a.nblocks), dim3(256), 0, st, a);
-}
-
-// Everything after the subsequence starts are known: symbols, inverse transforms, colour.
-static int khg_enqueue_decode_tail(khg_ctx* c, const KhgDecodeCall& call)
-{
-    hipStream_t st = call.st;
-    const KhgDecArgs& d = call.d;
-    hipLaunchKernelGGL(khg_dec_write_kernel, dim3(d.nblocks), dim3(256), 0, st, d);
-    KhgFwdGrid gr;
-    for (int p = 0; p < 3; ++p) {  // Decompress.h:274-276
-        KhgInvArgs a = khg_inv_args(c->ws, c->dws, call.rows, call.cols, p, 2, &gr);
-        hipLaunchKernelGGL((khg_inv_kernel<2>), dim3(gr.nstrip * gr.nseg), dim3(256), 0, st, a);
-    }
-    for (int p = 0; p < 3; ++p) {  // Decompress.h:278-280
-        KhgInvArgs a = khg_inv_args(c->ws, c->dws, call.rows, call.cols, p, 1, &gr);
-        hipLaunchKernelGGL((khg_inv_kernel<1>), dim3(gr.nstrip * gr.nseg), dim3(256), 0, st, a);
-    }
-    KhgRgbArgs ra;
-    ra.y = c->dws.plane[0]; ra.cb = c->dws.plane[1]; ra.cr = c->dws.plane[2];
-    ra.r = call.r; ra.g = call.g; ra.b = call.b;
-    ra.rows = call.rows; ra.cols = call.cols;
-    size_t quads = (size_t)call.rows * call.cols / 4;
-    unsigned grid = (unsigned)((quads + 255) / 256 < 8192 ? (quads + 255) / 256 : 8192);
-    hipLaunchKernelGGL(khg_rgb_kernel, dim3(grid), dim3(256), 0, st, ra);
-    KHG_HIP(hipGetLastError());
-    KHG_HIP(hipMemcpyAsync(c->h_res, c->ws.res, sizeof(KhgResult), hipMemcpyDeviceToHost, st));
-    KHG_HIP(hipEventRecord(c->done, st));
-    return KHG_OK;
-}
-
 extern "C" int khg_decode_dev(khg_ctx* c, const uint8_t* d_comp, size_t len, int rows, int cols, uint8_t* d_r,
                               uint8_t* d_g, uint8_t* d_b, void* stream)
 {
@@ -79,63 +44,43 @@ extern "C" int khg_decode_dev(khg_ctx* c, const uint8_t* d_comp, size_t len, int
     if (len < 36 + 24) return KHG_ERR_FORMAT;
     hipStream_t st = (hipStream_t)stream;
     KHG_HIP(hipSetDevice(c->device));
-    KhgDecodeCall& call = c->dec_call;
-    call.d = khg_dec_args(c->ws, c->dws, d_comp, len, rows, cols);
-    call.r = d_r; call.g = d_g; call.b = d_b;
-    call.rows = rows; call.cols = cols;
-    call.st = st;
+    const KhgDecArgs d = khg_dec_args(c->ws, c->dws, d_comp, len, rows, cols);
     KHG_HIP(hipMemsetAsync(c->ws.res, 0, sizeof(KhgResult), st));
-    hipLaunchKernelGGL(khg_dec_header_kernel, dim3(1), dim3(256), 0, st, call.d);
-    hipLaunchKernelGGL(khg_dec_tree_kernel, dim3(3), dim3(256), 0, st, call.d);
-    khg_launch_sync_pass(call.d, 0, st);
-    hipLaunchKernelGGL(khg_dec_fix_kernel, dim3((call.d.nblocks + 255) / 256), dim3(256), 0, st, call.d);
-    hipLaunchKernelGGL(khg_dec_scan_kernel, dim3(1), dim3(1024), 0, st, call.d);
-    rc = khg_enqueue_decode_tail(c, call);
-    if (rc) return rc;
+    hipLaunchKernelGGL(khg_dec_header_kernel, dim3(1), dim3(256), 0, st, d);
+    hipLaunchKernelGGL(khg_dec_tree_kernel, dim3(3), dim3(256), 0, st, d);
+    hipLaunchKernelGGL(khg_dec_map_kernel, dim3(d.nblocks), dim3(256), 0, st, d);
+    hipLaunchKernelGGL(khg_dec_chain_kernel, dim3(3), dim3(256), 0, st, d);
+    hipLaunchKernelGGL(khg_dec_write_kernel, dim3(d.nblocks), dim3(256), 0, st, d);
+    KhgFwdGrid gr;
+    for (int p = 0; p < 3; ++p) {  // Decompress.h:274-276
+        KhgInvArgs a = khg_inv_args(c->ws, c->dws, rows, cols, p, 2, &gr);
+        hipLaunchKernelGGL((khg_inv_kernel<2>), dim3(gr.nstrip * gr.nseg), dim3(256), 0, st, a);
+    }
+    for (int p = 0; p < 3; ++p) {  // Decompress.h:278-280
+        KhgInvArgs a = khg_inv_args(c->ws, c->dws, rows, cols, p, 1, &gr);
+        hipLaunchKernelGGL((khg_inv_kernel<1>), dim3(gr.nstrip * gr.nseg), dim3(256), 0, st, a);
+    }
+    KhgRgbArgs ra;
+    ra.y = c->dws.plane[0]; ra.cb = c->dws.plane[1]; ra.cr = c->dws.plane[2];
+    ra.r = d_r; ra.g = d_g; ra.b = d_b;
+    ra.rows = rows; ra.cols = cols;
+    unsigned grid = (unsigned)(rows < 4096 ? rows : 4096);
+    hipLaunchKernelGGL(khg_rgb_kernel, dim3(grid), dim3(256), 0, st, ra);
+    KHG_HIP(hipGetLastError());
+    KHG_HIP(hipMemcpyAsync(c->h_res, c->ws.res, sizeof(KhgResult), hipMemcpyDeviceToHost, st));
+    KHG_HIP(hipEventRecord(c->done, st));
     c->last_stream = st;
     c->pending = 2;
     return KHG_OK;
-}
-
-// Waits for the last decode.  If a workgroup's first thread, re-run from its exact start, did not
-// rejoin its speculative run (e.g. fixed-length codes never resynchronise), chained sync passes
-// are run here until no workgroup's arrival changes any more, then the tail is re-enqueued.
-static int khg_finish_decode(khg_ctx* c)
-{
-    KHG_HIP(hipEventSynchronize(c->done));
-    int status = c->h_res->status;
-    if (status != KHG_NOT_CONVERGED) return status;
-    KhgDecodeCall& call = c->dec_call;
-    hipStream_t st = call.st;
-    for (uint32_t pass = 1; pass < call.d.nblocks + 3; ++pass) {
-        KHG_HIP(hipMemsetAsync(c->ws.res, 0, sizeof(KhgResult), st));
-        KHG_HIP(hipMemsetAsync(call.d.mismatch, 0, sizeof(uint32_t), st));
-        khg_launch_sync_pass(call.d, (int)pass, st);
-        hipLaunchKernelGGL(khg_dec_scan_kernel, dim3(1), dim3(1024), 0, st, call.d);
-        KHG_HIP(hipMemcpyAsync(c->h_res, c->ws.res, sizeof(KhgResult), hipMemcpyDeviceToHost, st));
-        KHG_HIP(hipStreamSynchronize(st));
-        if (c->h_res->status != KHG_NOT_CONVERGED) break;
-    }
-    if (c->h_res->status != 0) return c->h_res->status == KHG_NOT_CONVERGED ? KHG_ERR_FORMAT : c->h_res->status;
-    int rc = khg_enqueue_decode_tail(c, call);
-    if (rc) return rc;
-    KHG_HIP(hipEventSynchronize(c->done));
-    return c->h_res->status;
 }
 
 extern "C" int khg_last_status(khg_ctx* c)
 {
     if (!c) return KHG_ERR_ARG;
     if (!c->pending) return KHG_OK;
-    int rc;
-    if (c->pending == 2) {
-        rc = khg_finish_decode(c);
-    } else {
-        KHG_HIP(hipEventSynchronize(c->done));
-        rc = c->h_res->status;
-    }
+    KHG_HIP(hipEventSynchronize(c->done));
     c->pending = 0;
-    return rc;
+    return c->h_res->status;
 }
 
 extern "C" int khg_decode(khg_ctx* c, const uint8_t* comp, size_t len, uint8_t* r, uint8_t* g, uint8_t* b)

@@ -67,21 +67,16 @@ __global__ __launch_bounds__(256) void khg_dec_tree_kernel(KhgDecArgs a)
     khg_dec_tree_body(a, (int)blockIdx.x, sh);
 }
 
-__global__ __launch_bounds__(256) void khg_dec_sync_kernel(KhgDecArgs a)
+__global__ __launch_bounds__(256) void khg_dec_map_kernel(KhgDecArgs a)
 {
     __shared__ KhgDecSmem sh;
-    khg_dec_sync_body(a, blockIdx.x, sh);
+    khg_dec_map_body(a, blockIdx.x, sh);
 }
 
-__global__ __launch_bounds__(256) void khg_dec_fix_kernel(KhgDecArgs a)
+__global__ __launch_bounds__(256) void khg_dec_chain_kernel(KhgDecArgs a)
 {
-    khg_dec_fix_body(a, blockIdx.x);
-}
-
-__global__ __launch_bounds__(1024) void khg_dec_scan_kernel(KhgDecArgs a)
-{
-    __shared__ KhgDecScanSmem sh;
-    khg_dec_scan_body(a, sh);
+    __shared__ KhgDecChainSmem sh;
+    khg_dec_chain_body(a, (int)blockIdx.x, sh);
 }
 
 __global__ __launch_bounds__(256) void khg_dec_write_kernel(KhgDecArgs a)
@@ -120,19 +115,11 @@ __global__ __launch_bounds__(256) void khg_sse_kernel(KhgSseArgs a)
         }                                                                                               \
     } while (0)
 
-struct KhgDecodeCall {
-    KhgDecArgs d;
-    uint8_t *r, *g, *b;
-    int rows, cols;
-    hipStream_t st;
-};
-
 struct khg_ctx {
     int device;
     int max_rows, max_cols;
     KhgWorkspace ws;
     KhgDecWorkspace dws;
-    KhgDecodeCall dec_call;  // arguments of the last decode (for the rare extra sync passes)
     void* slab;          // one device allocation carved into the workspace
     size_t slab_bytes;
     KhgResult* h_res;    // pinned host copy of ws.res
@@ -199,7 +186,7 @@ extern "C" int khg_ctx_create(int device, int max_rows, int max_cols, khg_ctx** 
     size_t o_cb = take(s.chunk_bits), o_co = take(s.chunk_off), o_res = take(sizeof(KhgResult));
     size_t o_plane[3];
     for (int p = 0; p < 3; ++p) o_plane[p] = take(ds.plane[p]);
-    size_t o_lut = take(ds.lut), o_sub = take(ds.sub), o_blk = take(ds.blk), o_masks = take(ds.masks), o_hdr = take(sizeof(KhgDecHeader));
+    size_t o_lut = take(ds.lut), o_blk = take(ds.blk), o_submap = take(ds.submap), o_hdr = take(sizeof(KhgDecHeader));
     size_t o_ssim = take(nblk * sizeof(double)), o_sse = take(64);
     c->slab_bytes = total;
     if (hipMalloc(&c->slab, total) != hipSuccess) { delete c; return KHG_ERR_NOMEM; }
@@ -213,9 +200,8 @@ extern "C" int khg_ctx_create(int device, int max_rows, int max_cols, khg_ctx** 
     c->ws.res = (KhgResult*)(base + o_res);
     for (int p = 0; p < 3; ++p) c->dws.plane[p] = (double*)(base + o_plane[p]);
     c->dws.lut = (uint32_t*)(base + o_lut);
-    c->dws.sub = (KhgSubInfo*)(base + o_sub);
     c->dws.blk = (KhgBlkInfo*)(base + o_blk);
-    c->dws.masks = (uint32_t*)(base + o_masks);
+    c->dws.submap = (uint16_t*)(base + o_submap);
     c->dws.hdr = (KhgDecHeader*)(base + o_hdr);
     c->ssim_blocks = (double*)(base + o_ssim);
     c->sse = (unsigned long long*)(base + o_sse);

@@ -37,9 +37,8 @@ struct SimWs {
         khg_dec_workspace_sizes(rows, cols, &d);
         for (int p = 0; p < 3; ++p) dws.plane[p] = alloc<double>(d.plane[p]);
         dws.lut = alloc<uint32_t>(d.lut);
-        dws.sub = alloc<KhgSubInfo>(d.sub);
         dws.blk = alloc<KhgBlkInfo>(d.blk);
-        dws.masks = alloc<uint32_t>(d.masks);
+        dws.submap = alloc<uint16_t>(d.submap);
         dws.hdr = alloc<KhgDecHeader>(sizeof(KhgDecHeader));
     }
     KhgDecWorkspace dws;
@@ -108,7 +107,7 @@ int khgsim_encode(const uint8_t* r, const uint8_t* g, const uint8_t* b, int rows
     return S.ws.res->status;
 }
 
-// Mirrors khg_decode_dev + khg_finish_decode.  max_passes = 0 means "as many as needed".
+// Mirrors khg_decode_dev.
 int khgsim_decode(const uint8_t* comp, size_t len, int rows, int cols, uint8_t* r, uint8_t* g, uint8_t* b,
                   int16_t* qy, int16_t* qcb, int16_t* qcr, int* passes_used) {
     if (!khg_dims_ok(rows, cols)) return -1;
@@ -122,21 +121,10 @@ int khgsim_decode(const uint8_t* comp, size_t len, int rows, int cols, uint8_t* 
     for (int p = 0; p < 3; ++p) khg_dec_tree_body(d, p, *tsh);
     delete tsh;
     KhgDecSmem* lsh = new KhgDecSmem;
-    KhgDecScanSmem* ssh = new KhgDecScanSmem;
-    int pass = 0;
-    d.pass = 0;
-    for (uint32_t b_ = 0; b_ < d.nblocks; ++b_) khg_dec_sync_body(d, b_, *lsh);
-    for (uint32_t b_ = 0; b_ < (d.nblocks + 255) / 256; ++b_) khg_dec_fix_body(d, b_);
-    khg_dec_scan_body(d, *ssh);
-    while (S.ws.res->status == KHG_NOT_CONVERGED && pass <= (int)d.nblocks + 3) {
-        ++pass;
-        S.ws.res->status = 0;
-        d.mismatch[0] = 0;
-        d.pass = pass;
-        for (uint32_t b_ = 0; b_ < d.nblocks; ++b_) khg_dec_sync_body(d, b_, *lsh);
-        khg_dec_scan_body(d, *ssh);
-    }
-    if (passes_used) *passes_used = pass + 1;
+    KhgDecChainSmem* ssh = new KhgDecChainSmem;
+    for (uint32_t b_ = 0; b_ < d.nblocks; ++b_) khg_dec_map_body(d, b_, *lsh);
+    for (int p = 0; p < 3; ++p) khg_dec_chain_body(d, p, *ssh);
+    if (passes_used) *passes_used = 1;
     for (uint32_t b_ = 0; b_ < d.nblocks; ++b_) khg_dec_write_body(d, b_, *lsh);
     delete lsh;
     delete ssh;

@@ -79,10 +79,12 @@ def test_decode_dev_async(codec):
     assert np.array_equal(dec.cpu().numpy(), O.decode(out[:n].cpu().numpy().tobytes()))
 
 
-def test_fixed_length_codes_need_extra_sync_passes(codec):
-    """Four equiprobable symbols give 2-bit codes that never self-synchronise from an odd
-    offset: the speculative two-pass decode must detect it and still return exact pixels."""
+def test_fixed_length_codes(codec):
+    """3-bit codes only (never self-synchronising) and a noise image: exact pixels either way."""
+    import craft
     import oracle_py as O
+    comp = craft.fixed_length_comp(1024, 1024, 1)
+    assert np.array_equal(codec.decode(comp), O.decode(comp))
     rng = np.random.default_rng(3)
     rgb = rng.integers(0, 256, (3, 1024, 1024), dtype=np.uint8)
     comp = O.encode(rgb, 2)

@@ -35,7 +35,7 @@ def test_run_images(run_images, name, lvl):
     rc, comp = S.encode(rgb, lvl)
     assert rc == 0 and comp == O.encode(rgb, lvl)
     rc, out, q, passes = S.decode(comp, rgb.shape[1], rgb.shape[2])
-    assert rc == 0 and passes == 1  # speculative pass + fix was enough
+    assert rc == 0
     assert np.array_equal(out, O.decode(comp))
     assert S.ssim(rgb[0], out[0]) == O.ssim(rgb[0], out[0])
 
@@ -60,10 +60,12 @@ def test_decode_reference_files():
         assert rc == 0 and np.array_equal(out, O.decode(comp))
 
 
-def test_decode_fixed_length_codes_takes_extra_passes():
-    comp = craft.fixed_length_comp(512, 512, 1)  # 786432 luma bits = 1536 subsequences = 6 workgroups
-    rc, out, _, passes = S.decode(comp, 512, 512)
-    assert rc == 0 and passes > 1
+def test_decode_fixed_length_codes():
+    """3-bit codes only: a decoder started at a wrong offset never resynchronises, so the
+    per-offset maps (not self-synchronisation) must carry the exact starts across 6 workgroups."""
+    comp = craft.fixed_length_comp(512, 512, 1)  # 786432 luma bits = 1536 subsequences
+    rc, out, _, _ = S.decode(comp, 512, 512)
+    assert rc == 0
     assert np.array_equal(out, O.decode(comp))
 
 
