@@ -21,6 +21,7 @@ static inline KhgDecArgs khg_dec_args(const KhgWorkspace& ws, const KhgDecWorksp
     d.tree_left = ws.tree_left; d.tree_right = ws.tree_right; d.tree_root = ws.tree_root;
     d.big_scratch = ws.big_scratch;
     d.lut = dws.lut;
+    d.lut2 = dws.lut2;
     uint32_t ny = (uint32_t)((size_t)rows * cols), nc = ny / 4;
     d.n[0] = ny; d.n[1] = nc; d.n[2] = nc;
     uint32_t blk = 0;

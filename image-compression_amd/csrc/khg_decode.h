@@ -32,6 +32,8 @@ enum {
     KHG_STAGE_LDS = KHG_STAGE_WORDS + KHG_STAGE_WORDS / 32 + 1,  // one pad word per 32: threads read 16 words apart
     KHG_LUT_BITS = 12,
     KHG_LUT_SIZE = 1 << KHG_LUT_BITS,
+    KHG_LUT2_BITS = 8,        // second-level tables: the next 8 bits after a first-level miss
+    KHG_LUT2_SIZE = 1 << KHG_LUT2_BITS,
     KHG_MAXOFF = KHG_MAX_CODE_BITS,  // start offsets 0..55
     KHG_OFF_TEMP = 62,        // map entry not final yet: the count field holds the landing offset
     KHG_OFF_NONE = 63         // no codeword starts from here on (the stream has ended)
@@ -70,13 +72,14 @@ struct KhgBlkInfo {
 struct KhgDecWorkspace {
     double* plane[3];   // reconstructed Y / Cb / Cr (f64)
     uint32_t* lut;      // [3][KHG_LUT_SIZE] first-level decode tables
+    uint32_t* lut2;     // [3][KHG_LUT_SIZE][KHG_LUT2_SIZE] second-level tables (only rows of missing prefixes are filled)
     KhgBlkInfo* blk;    // per workgroup, planes concatenated
     uint16_t* submap;   // [workgroup][KHG_MAXOFF][KHG_DEC_BLOCK] subsequence maps
     KhgDecHeader* hdr;
 };
 
 struct KhgDecWorkspaceSizes {
-    size_t plane[3], lut, blk, submap;
+    size_t plane[3], lut, lut2, blk, submap;
 };
 
 static inline uint32_t khg_max_blocks(uint64_t nsym)
@@ -100,6 +103,7 @@ struct KhgDecArgs {
     int32_t* tree_root;    // [3]
     uint32_t* big_scratch;
     uint32_t* lut;         // [3][KHG_LUT_SIZE]
+    uint32_t* lut2;        // [3][KHG_LUT_SIZE][KHG_LUT2_SIZE]
     KhgBlkInfo* blk;       // [nblocks]
     uint16_t* submap;      // [nblocks][KHG_MAXOFF][KHG_DEC_BLOCK]
     uint32_t blk0[3];      // first workgroup index of each plane (capacity layout)
@@ -115,6 +119,7 @@ static inline void khg_dec_workspace_sizes(int rows, int cols, KhgDecWorkspaceSi
     s->plane[1] = s->plane[2] = nc * sizeof(double);
     size_t blocks = (size_t)khg_max_blocks(ny) + 2 * (size_t)khg_max_blocks(nc);
     s->lut = 3 * (size_t)KHG_LUT_SIZE * sizeof(uint32_t);
+    s->lut2 = 3 * (size_t)KHG_LUT_SIZE * KHG_LUT2_SIZE * sizeof(uint32_t);
     s->blk = blocks * sizeof(KhgBlkInfo);
     s->submap = blocks * KHG_MAXOFF * KHG_DEC_BLOCK * sizeof(uint16_t);
 }
@@ -177,6 +182,7 @@ struct KhgDecTreeSmem {
     alignas(16) uint32_t w[6 * KHG_TREE_LDS_K + 8];
     int32_t root;
     int maxlen;
+    uint32_t nmiss;
 };
 
 // Depth of a leaf = length of its code (Huffman.h:57-68).
@@ -192,8 +198,9 @@ KHG_DEV int khg_leaf_depth(const uint32_t* parent, int leaf, int root)
 
 // bid = colour component.  Rebuilds the tree from the stored table with the encoder's own
 // construction (Decompress.h:45-47), finds the longest code and fills the first-level decode table.
-// LUT entry: bit 31 set = leaf reached within KHG_LUT_BITS bits: bits 16..23 code length,
-// bits 0..15 symbol (int16); otherwise the entry is the node reached after KHG_LUT_BITS bits.
+// LUT entry: bit 31 set = leaf reached: bits 16..23 code length, bits 0..15 symbol (int16);
+// otherwise the entry is the node reached after KHG_LUT_BITS bits (first level) or after
+// KHG_LUT_BITS + KHG_LUT2_BITS bits (second level, one 256-entry table per missing 12-bit prefix).
 KHG_DEV void khg_dec_tree_body(const KhgDecArgs& a, int bid, KhgDecTreeSmem& sh)
 {
     KhgDecHeader* h = a.hdr;
@@ -214,7 +221,10 @@ KHG_DEV void khg_dec_tree_body(const KhgDecArgs& a, int bid, KhgDecTreeSmem& sh)
             tsym[i] = s;
             if (s < -32768 || s > 32767) khg_set_status(&a.res->status, -4);
         }
-        if (tid == 0) sh.maxlen = 0;
+        if (tid == 0) {
+            sh.maxlen = 0;
+            sh.nmiss = 0;
+        }
     }
     KHG_BARRIER();
     if (k <= KHG_TREE_LDS_K) {  // separate copies: LDS vs global address space of the heap arrays
@@ -276,9 +286,31 @@ KHG_DEV void khg_dec_tree_body(const KhgDecArgs& a, int bid, KhgDecTreeSmem& sh)
                     ++d;
                 }
                 if (left[node] < 0) e = 0x80000000u | ((uint32_t)d << 16) | (uint32_t)(uint16_t)(int16_t)tsym[node];
-                else e = (uint32_t)node;
+                else {
+                    e = (uint32_t)node;
+                    sh.w[khg_atomic_add(&sh.nmiss, 1u)] = (uint32_t)v;  // the heap arrays are dead by now
+                }
             }
             lut[v] = e;
+        }
+    }
+    KHG_BARRIER();
+    KHG_FOR_THREADS(256)
+    {
+        // second level: 8 more bits below every missing prefix
+        uint32_t* lut2 = a.lut2 + (size_t)bid * KHG_LUT_SIZE * KHG_LUT2_SIZE;
+        const uint32_t total = sh.nmiss * KHG_LUT2_SIZE;
+        for (uint32_t j = (uint32_t)tid; j < total; j += 256) {
+            const uint32_t v = sh.w[j / KHG_LUT2_SIZE], x = j % KHG_LUT2_SIZE;
+            int node = (int)lut[v], d = 0;
+            while (d < KHG_LUT2_BITS && left[node] >= 0) {
+                node = ((x >> (KHG_LUT2_BITS - 1 - d)) & 1) ? right[node] : left[node];
+                ++d;
+            }
+            uint32_t e;
+            if (left[node] < 0) e = 0x80000000u | ((uint32_t)(KHG_LUT_BITS + d) << 16) | (uint32_t)(uint16_t)(int16_t)tsym[node];
+            else e = (uint32_t)node;
+            lut2[(size_t)v * KHG_LUT2_SIZE + x] = e;
         }
     }
 }
@@ -309,26 +341,33 @@ KHG_DEV int khg_block_plane(const KhgDecArgs& a, uint32_t blk)
 }
 
 // Decode one codeword at pos.  Returns its length (0 = the stream ends inside it) and symbol.
-KHG_DEV uint32_t khg_decode_one(const KhgBitsL& b, const uint32_t* lut, const int32_t* left, const int32_t* right,
-                                const int32_t* tsym, uint32_t pos, int* sym)
+KHG_DEV uint32_t khg_decode_one(const KhgBitsL& b, const uint32_t* lut, const uint32_t* lut2, const int32_t* left,
+                                const int32_t* right, const int32_t* tsym, uint32_t pos, int* sym)
 {
-    uint32_t window = b.peek32(pos);
-    uint32_t e = lut[window >> (32 - KHG_LUT_BITS)];
+    const uint32_t window = b.peek32(pos);
+    const uint32_t v = window >> (32 - KHG_LUT_BITS);
+    uint32_t e = lut[v];
     uint32_t len;
     if (e & 0x80000000u) {
         len = (e >> 16) & 0xFF;
         *sym = (int)(int16_t)(e & 0xFFFF);
     } else {
-        // code longer than KHG_LUT_BITS: continue the walk of Huffman.h:39-51 bit by bit
-        int node = (int)e;
-        len = KHG_LUT_BITS;
-        while (left[node] >= 0) {
-            if (pos + len >= b.nbits) return 0;
-            uint32_t bit = b.peek32(pos + len) >> 31;
-            node = bit ? right[node] : left[node];
-            ++len;
+        e = lut2[(size_t)v * KHG_LUT2_SIZE + ((window >> (32 - KHG_LUT_BITS - KHG_LUT2_BITS)) & (KHG_LUT2_SIZE - 1))];
+        if (e & 0x80000000u) {
+            len = (e >> 16) & 0xFF;
+            *sym = (int)(int16_t)(e & 0xFFFF);
+        } else {
+            // code longer than 20 bits: continue the walk of Huffman.h:39-51 bit by bit
+            int node = (int)e;
+            len = KHG_LUT_BITS + KHG_LUT2_BITS;
+            while (left[node] >= 0) {
+                if (pos + len >= b.nbits) return 0;
+                uint32_t bit = b.peek32(pos + len) >> 31;
+                node = bit ? right[node] : left[node];
+                ++len;
+            }
+            *sym = tsym[node];
         }
-        *sym = tsym[node];
     }
     if (pos + len > b.nbits) return 0;
     return len;
@@ -379,6 +418,7 @@ KHG_DEV void khg_dec_map_body(const KhgDecArgs& a, uint32_t blk, KhgDecSmem& sh)
     const int32_t* left = a.tree_left + (size_t)p * 2 * KHG_NBINS;
     const int32_t* right = a.tree_right + (size_t)p * 2 * KHG_NBINS;
     const int32_t* tsym = a.tab_sym + (size_t)p * KHG_NBINS;
+    const uint32_t* lut2 = a.lut2 + (size_t)p * KHG_LUT_SIZE * KHG_LUT2_SIZE;
     const KhgBitsL bits = khg_dec_stage(a, p, blk_begin, sh);
     KHG_BARRIER();
 
@@ -394,7 +434,7 @@ KHG_DEV void khg_dec_map_body(const KhgDecArgs& a, uint32_t blk, KhgDecSmem& sh)
             uint16_t e = khg_map_entry(KHG_OFF_NONE, 0);
             if (pos < end) {
                 int s;
-                uint32_t len = khg_decode_one(bits, sh.lut, left, right, tsym, pos, &s);
+                uint32_t len = khg_decode_one(bits, sh.lut, lut2, left, right, tsym, pos, &s);
                 if (len) e = khg_map_entry(KHG_OFF_TEMP, o + len);  // landing offset < 2 * 56
             }
             map[o * KHG_DEC_BLOCK] = e;
@@ -420,7 +460,7 @@ KHG_DEV void khg_dec_map_body(const KhgDecArgs& a, uint32_t blk, KhgDecSmem& sh)
                         cur = 0;
                     }
                     int s;
-                    uint32_t len = khg_decode_one(bits, sh.lut, left, right, tsym, pos, &s);
+                    uint32_t len = khg_decode_one(bits, sh.lut, lut2, left, right, tsym, pos, &s);
                     if (len == 0) {
                         dead = true;
                         break;
@@ -449,7 +489,7 @@ KHG_DEV void khg_dec_map_body(const KhgDecArgs& a, uint32_t blk, KhgDecSmem& sh)
                         break;
                     }
                     int s;
-                    uint32_t len = khg_decode_one(bits, sh.lut, left, right, tsym, pos, &s);
+                    uint32_t len = khg_decode_one(bits, sh.lut, lut2, left, right, tsym, pos, &s);
                     if (len == 0) {
                         dead = true;
                         break;
@@ -573,6 +613,7 @@ KHG_DEV void khg_dec_write_body(const KhgDecArgs& a, uint32_t blk, KhgDecSmem& s
     const int32_t* left = a.tree_left + (size_t)p * 2 * KHG_NBINS;
     const int32_t* right = a.tree_right + (size_t)p * 2 * KHG_NBINS;
     const int32_t* tsym = a.tab_sym + (size_t)p * KHG_NBINS;
+    const uint32_t* lut2 = a.lut2 + (size_t)p * KHG_LUT_SIZE * KHG_LUT2_SIZE;
     uint32_t* s_off = sh.mask;                       // the codeword-start maps are not needed here:
     uint32_t* s_cnt = sh.mask + KHG_DEC_BLOCK;       // their space holds start offset, count and
     uint32_t* s_pre = sh.mask + 2 * KHG_DEC_BLOCK;   // count prefix of every subsequence
@@ -620,11 +661,34 @@ KHG_DEV void khg_dec_write_body(const KhgDecArgs& a, uint32_t blk, KhgDecSmem& s
             for (int g = 0; g < (tid >> 4); ++g) o += sh.grp[g];
             uint32_t pos = blk_begin + (uint32_t)tid * KHG_SUB_BITS + off;
             int16_t* q = a.sym[p];
-            for (uint32_t i = 0; i < cnt; ++i) {
+            const uint32_t lim = a.n[p];
+            uint32_t i = 0;
+            // single stores up to an 8-byte boundary, then four symbols per store
+            for (; i < cnt && ((o + i) & 3u); ++i) {
                 int s;
-                uint32_t len = khg_decode_one(bits, sh.lut, left, right, tsym, pos, &s);
+                uint32_t len = khg_decode_one(bits, sh.lut, lut2, left, right, tsym, pos, &s);
+                if (len == 0) { i = cnt; break; }
+                if (o + i < lim) q[o + i] = (int16_t)s;
+                pos += len;
+            }
+            for (; i + 4 <= cnt && o + i + 4 <= lim; i += 4) {
+                uint64_t pack = 0;
+                bool dead = false;
+                for (int j = 0; j < 4; ++j) {
+                    int s;
+                    uint32_t len = khg_decode_one(bits, sh.lut, lut2, left, right, tsym, pos, &s);
+                    if (len == 0) { dead = true; break; }
+                    pack |= (uint64_t)(uint16_t)(int16_t)s << (16 * j);
+                    pos += len;
+                }
+                if (dead) { i = cnt; break; }  // cannot happen: cnt counts whole codewords
+                *(uint64_t*)(q + o + i) = pack;
+            }
+            for (; i < cnt; ++i) {
+                int s;
+                uint32_t len = khg_decode_one(bits, sh.lut, lut2, left, right, tsym, pos, &s);
                 if (len == 0) break;
-                if (o + i < a.n[p]) q[o + i] = (int16_t)s;
+                if (o + i < lim) q[o + i] = (int16_t)s;
                 pos += len;
             }
         }

@@ -186,7 +186,7 @@ extern "C" int khg_ctx_create(int device, int max_rows, int max_cols, khg_ctx** 
     size_t o_cb = take(s.chunk_bits), o_co = take(s.chunk_off), o_res = take(sizeof(KhgResult));
     size_t o_plane[3];
     for (int p = 0; p < 3; ++p) o_plane[p] = take(ds.plane[p]);
-    size_t o_lut = take(ds.lut), o_blk = take(ds.blk), o_submap = take(ds.submap), o_hdr = take(sizeof(KhgDecHeader));
+    size_t o_lut = take(ds.lut), o_lut2 = take(ds.lut2), o_blk = take(ds.blk), o_submap = take(ds.submap), o_hdr = take(sizeof(KhgDecHeader));
     size_t o_ssim = take(nblk * sizeof(double)), o_sse = take(64);
     c->slab_bytes = total;
     if (hipMalloc(&c->slab, total) != hipSuccess) { delete c; return KHG_ERR_NOMEM; }
@@ -200,6 +200,7 @@ extern "C" int khg_ctx_create(int device, int max_rows, int max_cols, khg_ctx** 
     c->ws.res = (KhgResult*)(base + o_res);
     for (int p = 0; p < 3; ++p) c->dws.plane[p] = (double*)(base + o_plane[p]);
     c->dws.lut = (uint32_t*)(base + o_lut);
+    c->dws.lut2 = (uint32_t*)(base + o_lut2);
     c->dws.blk = (KhgBlkInfo*)(base + o_blk);
     c->dws.submap = (uint16_t*)(base + o_submap);
     c->dws.hdr = (KhgDecHeader*)(base + o_hdr);

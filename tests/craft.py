@@ -48,3 +48,20 @@ def fixed_length_comp(rows, cols, lvl, seed=0):
     counts[:] = n // 8
     zero = (np.array([n // 4], np.int32), np.array([0], np.int32), [])
     return make_comp(rows, cols, lvl, [(counts, syms, seq), zero, zero])
+
+
+def long_code_comp(rows, cols, lvl, depth=30, seed=0):
+    """Luma table with Fibonacci counts: code lengths 1..depth (beyond both decode-table levels);
+    every symbol occurs, the rare ones a few times.  Chroma planes hold the single symbol 0."""
+    rng = np.random.default_rng(seed)
+    n = rows * cols
+    fib = [1, 1]
+    while len(fib) < depth + 1:
+        fib.append(fib[-1] + fib[-2])
+    counts = np.array(fib[:depth + 1], np.int64)
+    syms = np.arange(depth + 1, dtype=np.int32) - depth // 2
+    p = counts / counts.sum()
+    seq = syms[rng.choice(depth + 1, n, p=p)]
+    seq[rng.choice(n, 4 * (depth + 1), replace=False)] = np.tile(syms, 4)  # every code length shows up
+    zero = (np.array([n // 4], np.int32), np.array([0], np.int32), [])
+    return make_comp(rows, cols, lvl, [(counts.astype(np.int32), syms, seq), zero, zero])

@@ -37,6 +37,7 @@ struct SimWs {
         khg_dec_workspace_sizes(rows, cols, &d);
         for (int p = 0; p < 3; ++p) dws.plane[p] = alloc<double>(d.plane[p]);
         dws.lut = alloc<uint32_t>(d.lut);
+        dws.lut2 = alloc<uint32_t>(d.lut2);
         dws.blk = alloc<KhgBlkInfo>(d.blk);
         dws.submap = alloc<uint16_t>(d.submap);
         dws.hdr = alloc<KhgDecHeader>(sizeof(KhgDecHeader));

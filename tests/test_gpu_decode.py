@@ -91,6 +91,14 @@ def test_fixed_length_codes(codec):
     assert np.array_equal(codec.decode(comp), O.decode(comp))
 
 
+def test_long_codes(codec):
+    """Code lengths up to 30 bits exercise both decode-table levels and the bitwise tail."""
+    import craft
+    import oracle_py as O
+    comp = craft.long_code_comp(512, 512, 1)
+    assert np.array_equal(codec.decode(comp), O.decode(comp))
+
+
 def test_malformed_files_are_rejected(codec):
     import oracle_py as O
     from khugle_amd import synth_frame, KhgError

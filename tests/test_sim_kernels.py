@@ -69,6 +69,16 @@ def test_decode_fixed_length_codes():
     assert np.array_equal(out, O.decode(comp))
 
 
+def test_decode_long_codes():
+    """Code lengths up to 30 bits: first-level table, second-level table and the bitwise tail."""
+    comp = craft.long_code_comp(128, 128, 1)
+    rc, out, q, _ = S.decode(comp, 128, 128)
+    assert rc == 0
+    (wq, _) = O.decode_planes(comp)
+    assert np.array_equal(q[0].astype(np.int32), wq[0])
+    assert np.array_equal(out, O.decode(comp))
+
+
 def test_output_capacity_is_checked():
     rgb = synth_frame(64, 64, 1, 0)
     rc, _ = S.encode(rgb, 0, cap=64)
