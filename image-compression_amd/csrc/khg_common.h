@@ -23,6 +23,7 @@ static inline uint32_t khg_atomic_add(uint32_t* p, uint32_t v) { uint32_t o = *p
 static inline uint32_t khg_atomic_min(uint32_t* p, uint32_t v) { uint32_t o = *p; if (v < o) *p = v; return o; }
 static inline uint32_t khg_atomic_or(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o | v; return o; }
 static inline int khg_atomic_max_i(int* p, int v) { int o = *p; if (v > o) *p = v; return o; }
+static inline void khg_lds_or(uint32_t* p, uint32_t v) { *p |= v; }
 static inline uint32_t khg_bswap32(uint32_t v) { return __builtin_bswap32(v); }
 #else
 #include <hip/hip_runtime.h>
@@ -36,6 +37,7 @@ __device__ __forceinline__ uint32_t khg_atomic_add(uint32_t* p, uint32_t v) { re
 __device__ __forceinline__ uint32_t khg_atomic_min(uint32_t* p, uint32_t v) { return atomicMin(p, v); }
 __device__ __forceinline__ uint32_t khg_atomic_or(uint32_t* p, uint32_t v) { return atomicOr(p, v); }
 __device__ __forceinline__ int khg_atomic_max_i(int* p, int v) { return atomicMax(p, v); }
+__device__ __forceinline__ void khg_lds_or(uint32_t* p, uint32_t v) { atomicOr(p, v); }  // result unused: ds_or_b32, no wait
 __device__ __forceinline__ uint32_t khg_bswap32(uint32_t v) { return __builtin_bswap32(v); }
 #endif
 

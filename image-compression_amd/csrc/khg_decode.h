@@ -28,7 +28,7 @@ enum {
     KHG_SUB_WORDS = KHG_SUB_BITS / 32,
     KHG_DEC_BLOCK = 256,      // subsequences per workgroup
     KHG_BLK_BITS = KHG_SUB_BITS * KHG_DEC_BLOCK,
-    KHG_STAGE_WORDS = KHG_BLK_BITS / 32 + 4,  // a workgroup's span plus the longest overshoot
+    KHG_STAGE_WORDS = KHG_BLK_BITS / 32 + 8,  // a workgroup's span plus the longest overshoot and the cursor's read-ahead
     KHG_STAGE_LDS = KHG_STAGE_WORDS + KHG_STAGE_WORDS / 32 + 1,  // one pad word per 32: threads read 16 words apart
     KHG_LUT_BITS = 12,
     KHG_LUT_SIZE = 1 << KHG_LUT_BITS,
@@ -329,9 +329,9 @@ struct KhgBitsL {
     {
         uint32_t l = pos - bias;
         uint32_t w = l >> 5, s = l & 31;
-        uint32_t w0 = w < KHG_STAGE_WORDS ? stage[khg_stage_slot(w)] : 0;
-        uint32_t w1 = w + 1 < KHG_STAGE_WORDS ? stage[khg_stage_slot(w + 1)] : 0;
-        return s ? (w0 << s) | (w1 >> (32 - s)) : w0;
+        // callers stay inside the staged span: pos < span end + 56, and 8 spare words are staged
+        uint64_t two = ((uint64_t)stage[khg_stage_slot(w)] << 32) | stage[khg_stage_slot(w + 1)];
+        return (uint32_t)((two << s) >> 32);
     }
 };
 
@@ -370,6 +370,54 @@ KHG_DEV uint32_t khg_decode_one(const KhgBitsL& b, const uint32_t* lut, const ui
         }
     }
     if (pos + len > b.nbits) return 0;
+    return len;
+}
+
+// Sequential reader over the staged span: a 64-bit window kept in registers and topped up one
+// word at a time, so a codeword costs one table lookup and a few shifts.
+struct KhgCursor {
+    uint64_t buf;   // next stream bits, first bit in bit 63; at least 33 of them valid
+    uint32_t pos;   // stream position of bit 63
+    uint32_t next;  // next stage word to append
+    int avail;      // valid bits in buf
+};
+
+KHG_DEV void khg_cur_init(KhgCursor& c, const KhgBitsL& b, uint32_t pos)
+{
+    uint32_t l = pos - b.bias, w = l >> 5, s = l & 31;
+    uint64_t two = ((uint64_t)b.stage[khg_stage_slot(w)] << 32) | b.stage[khg_stage_slot(w + 1)];
+    c.buf = two << s;
+    c.avail = 64 - (int)s;
+    c.pos = pos;
+    c.next = w + 2;
+}
+
+// Decode the codeword at the cursor and step over it.  Returns its length (0 = the stream ends inside it).
+KHG_DEV uint32_t khg_cur_decode(KhgCursor& c, const KhgBitsL& b, const uint32_t* lut, const uint32_t* lut2,
+                                const int32_t* left, const int32_t* right, const int32_t* tsym, int* sym)
+{
+    const uint32_t top = (uint32_t)(c.buf >> 32);
+    const uint32_t v = top >> (32 - KHG_LUT_BITS);
+    uint32_t e = lut[v];
+    if (!(e & 0x80000000u)) {
+        e = lut2[(size_t)v * KHG_LUT2_SIZE + ((top >> (32 - KHG_LUT_BITS - KHG_LUT2_BITS)) & (KHG_LUT2_SIZE - 1))];
+        if (!(e & 0x80000000u)) {  // longer than 20 bits: bitwise tail, then re-seat the window
+            uint32_t len = khg_decode_one(b, lut, lut2, left, right, tsym, c.pos, sym);
+            if (len) khg_cur_init(c, b, c.pos + len);
+            return len;
+        }
+    }
+    const uint32_t len = (e >> 16) & 0xFF;  // <= 20
+    *sym = (int)(int16_t)(e & 0xFFFF);
+    if (c.pos + len > b.nbits) return 0;
+    c.buf <<= len;
+    c.avail -= (int)len;
+    c.pos += len;
+    if (c.avail <= 32) {
+        c.buf |= (uint64_t)b.stage[khg_stage_slot(c.next)] << (32 - c.avail);
+        c.avail += 32;
+        c.next++;
+    }
     return len;
 }
 
@@ -443,33 +491,38 @@ KHG_DEV void khg_dec_map_body(const KhgDecArgs& a, uint32_t blk, KhgDecSmem& sh)
         //    its codeword starts, later runs stop when they land on one of them
         bool have_main = false;
         uint32_t main_arr = KHG_OFF_NONE;
-        for (uint32_t oo = M; oo-- > 0;) {
-            const uint16_t e0 = map[oo * KHG_DEC_BLOCK];
-            if (khg_map_arr(e0) != KHG_OFF_TEMP || khg_map_cnt(e0) < M) continue;
+        // (every lane picks ITS next such offset per trip, so a wave runs its lanes' j-th runs
+        //  together: the long first runs side by side, then the short rejoining ones)
+        for (uint32_t oo = M;;) {
+            uint16_t e0 = 0;
+            bool found = false;
+            while (oo-- > 0) {
+                e0 = map[oo * KHG_DEC_BLOCK];
+                if (khg_map_arr(e0) == KHG_OFF_TEMP && khg_map_cnt(e0) >= M) {
+                    found = true;
+                    break;
+                }
+            }
+            if (!found) break;
             uint32_t pos = sub_begin + khg_map_cnt(e0), n = 1;
             bool joined = false, dead = false;
             const bool is_main = !have_main;
+            KhgCursor cur;
+            if (pos < end) khg_cur_init(cur, bits, pos);
             if (is_main) {
                 for (uint32_t w = 0; w < KHG_SUB_WORDS; ++w) mask[w * KHG_DEC_BLOCK] = 0;
-                uint32_t widx = 0xFFFFFFFFu, cur = 0;
                 while (pos < end) {
-                    uint32_t rel = pos - sub_begin, w = rel >> 5;
-                    if (w != widx) {
-                        if (widx != 0xFFFFFFFFu) mask[widx * KHG_DEC_BLOCK] = cur;
-                        widx = w;
-                        cur = 0;
-                    }
+                    const uint32_t rel = pos - sub_begin;
                     int s;
-                    uint32_t len = khg_decode_one(bits, sh.lut, lut2, left, right, tsym, pos, &s);
+                    uint32_t len = khg_cur_decode(cur, bits, sh.lut, lut2, left, right, tsym, &s);
                     if (len == 0) {
                         dead = true;
                         break;
                     }
-                    cur |= 0x80000000u >> (rel & 31);
+                    khg_lds_or(&mask[(rel >> 5) * KHG_DEC_BLOCK], 0x80000000u >> (rel & 31));
                     pos += len;
                     ++n;
                 }
-                if (widx != 0xFFFFFFFFu) mask[widx * KHG_DEC_BLOCK] = cur;
                 have_main = true;
             } else {
                 uint32_t widx = 0xFFFFFFFFu, mw = 0;
@@ -489,7 +542,7 @@ KHG_DEV void khg_dec_map_body(const KhgDecArgs& a, uint32_t blk, KhgDecSmem& sh)
                         break;
                     }
                     int s;
-                    uint32_t len = khg_decode_one(bits, sh.lut, lut2, left, right, tsym, pos, &s);
+                    uint32_t len = khg_cur_decode(cur, bits, sh.lut, lut2, left, right, tsym, &s);
                     if (len == 0) {
                         dead = true;
                         break;
@@ -662,34 +715,30 @@ KHG_DEV void khg_dec_write_body(const KhgDecArgs& a, uint32_t blk, KhgDecSmem& s
             uint32_t pos = blk_begin + (uint32_t)tid * KHG_SUB_BITS + off;
             int16_t* q = a.sym[p];
             const uint32_t lim = a.n[p];
+            KhgCursor cur;
+            khg_cur_init(cur, bits, pos);
             uint32_t i = 0;
             // single stores up to an 8-byte boundary, then four symbols per store
             for (; i < cnt && ((o + i) & 3u); ++i) {
                 int s;
-                uint32_t len = khg_decode_one(bits, sh.lut, lut2, left, right, tsym, pos, &s);
-                if (len == 0) { i = cnt; break; }
+                if (khg_cur_decode(cur, bits, sh.lut, lut2, left, right, tsym, &s) == 0) { i = cnt; break; }
                 if (o + i < lim) q[o + i] = (int16_t)s;
-                pos += len;
             }
             for (; i + 4 <= cnt && o + i + 4 <= lim; i += 4) {
                 uint64_t pack = 0;
                 bool dead = false;
                 for (int j = 0; j < 4; ++j) {
                     int s;
-                    uint32_t len = khg_decode_one(bits, sh.lut, lut2, left, right, tsym, pos, &s);
-                    if (len == 0) { dead = true; break; }
+                    if (khg_cur_decode(cur, bits, sh.lut, lut2, left, right, tsym, &s) == 0) { dead = true; break; }
                     pack |= (uint64_t)(uint16_t)(int16_t)s << (16 * j);
-                    pos += len;
                 }
                 if (dead) { i = cnt; break; }  // cannot happen: cnt counts whole codewords
                 *(uint64_t*)(q + o + i) = pack;
             }
             for (; i < cnt; ++i) {
                 int s;
-                uint32_t len = khg_decode_one(bits, sh.lut, lut2, left, right, tsym, pos, &s);
-                if (len == 0) break;
+                if (khg_cur_decode(cur, bits, sh.lut, lut2, left, right, tsym, &s) == 0) break;
                 if (o + i < lim) q[o + i] = (int16_t)s;
-                pos += len;
             }
         }
     }
