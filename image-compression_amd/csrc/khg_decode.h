@@ -51,6 +51,8 @@ struct KhgDecHeader {
     uint32_t stream_byte[3];  // byte offset of each plane's stream in the file
     uint32_t table_byte[3];   // byte offset of each plane's table
     int32_t maxlen[3];        // longest code of each plane
+    int32_t one_bit[3];       // value of the plane's 1-bit code (0 or 1), -1 if it has none
+    int32_t one_sym[3];       // its symbol
     int32_t lvl;
     int32_t rows, cols;
     int32_t ok;
@@ -273,6 +275,13 @@ KHG_DEV void khg_dec_tree_body(const KhgDecArgs& a, int bid, KhgDecTreeSmem& sh)
         const int root = sh.root;
         if (tid == 0) {
             h->maxlen[bid] = sh.maxlen;
+            int ob = -1, os = 0;
+            if (k > 1) {
+                if (left[left[root]] < 0) { ob = 0; os = tsym[left[root]]; }
+                else if (left[right[root]] < 0) { ob = 1; os = tsym[right[root]]; }
+            }
+            h->one_bit[bid] = ob;
+            h->one_sym[bid] = os;
             if (sh.maxlen > KHG_MAX_CODE_BITS) khg_set_status(&a.res->status, -4);
         }
         for (int v = tid; v < KHG_LUT_SIZE; v += 256) {
@@ -421,6 +430,37 @@ KHG_DEV uint32_t khg_cur_decode(KhgCursor& c, const KhgBitsL& b, const uint32_t*
     return len;
 }
 
+// Length (at most 32 and at most lim) of the run of 1-bit codewords `onebit` at the cursor; 0 if none.
+KHG_DEV uint32_t khg_cur_runlen(const KhgCursor& c, int onebit, uint32_t lim)
+{
+    if (onebit < 0) return 0;
+    const uint64_t x = onebit ? ~c.buf : c.buf;  // the run's bits read as zeros
+    uint32_t r = x ? (uint32_t)__builtin_clzll(x) : 64u;
+    r = r > 32u ? 32u : r;  // buf holds at least 33 valid bits
+    return r > lim ? lim : r;
+}
+
+// Step over r <= 32 bits.
+KHG_DEV void khg_cur_skip(KhgCursor& c, const KhgBitsL& b, uint32_t r)
+{
+    c.buf <<= r;
+    c.avail -= (int)r;
+    c.pos += r;
+    if (c.avail <= 32) {
+        c.buf |= (uint64_t)b.stage[khg_stage_slot(c.next)] << (32 - c.avail);
+        c.avail += 32;
+        c.next++;
+    }
+}
+
+// Positions rel .. rel+r-1 (r <= 32, inside the subsequence) as bits of the two mask words they touch.
+KHG_DEV uint64_t khg_mask_range(uint32_t rel, uint32_t r)
+{
+    const uint32_t b = rel & 31;
+    const uint64_t ones = r >= 32 ? 0xFFFFFFFFull : ((1ull << r) - 1);
+    return ones << (64 - b - r);
+}
+
 struct KhgDecSmem {
     uint32_t lut[KHG_LUT_SIZE];
     uint32_t stage[KHG_STAGE_LDS];
@@ -467,6 +507,7 @@ KHG_DEV void khg_dec_map_body(const KhgDecArgs& a, uint32_t blk, KhgDecSmem& sh)
     const int32_t* right = a.tree_right + (size_t)p * 2 * KHG_NBINS;
     const int32_t* tsym = a.tab_sym + (size_t)p * KHG_NBINS;
     const uint32_t* lut2 = a.lut2 + (size_t)p * KHG_LUT_SIZE * KHG_LUT2_SIZE;
+    const int onebit = a.hdr->one_bit[p];
     const KhgBitsL bits = khg_dec_stage(a, p, blk_begin, sh);
     KHG_BARRIER();
 
@@ -513,6 +554,16 @@ KHG_DEV void khg_dec_map_body(const KhgDecArgs& a, uint32_t blk, KhgDecSmem& sh)
                 for (uint32_t w = 0; w < KHG_SUB_WORDS; ++w) mask[w * KHG_DEC_BLOCK] = 0;
                 while (pos < end) {
                     const uint32_t rel = pos - sub_begin;
+                    const uint32_t r = khg_cur_runlen(cur, onebit, end - pos);
+                    if (r) {  // a run of 1-bit codewords: r starts at once
+                        const uint64_t m = khg_mask_range(rel, r);
+                        khg_lds_or(&mask[(rel >> 5) * KHG_DEC_BLOCK], (uint32_t)(m >> 32));
+                        if ((uint32_t)m) khg_lds_or(&mask[((rel >> 5) + 1) * KHG_DEC_BLOCK], (uint32_t)m);
+                        khg_cur_skip(cur, bits, r);
+                        pos += r;
+                        n += r;
+                        continue;
+                    }
                     int s;
                     uint32_t len = khg_cur_decode(cur, bits, sh.lut, lut2, left, right, tsym, &s);
                     if (len == 0) {
@@ -525,21 +576,31 @@ KHG_DEV void khg_dec_map_body(const KhgDecArgs& a, uint32_t blk, KhgDecSmem& sh)
                 }
                 have_main = true;
             } else {
-                uint32_t widx = 0xFFFFFFFFu, mw = 0;
                 while (pos < end) {
-                    uint32_t rel = pos - sub_begin, w = rel >> 5;
-                    if (w != widx) {
-                        widx = w;
-                        mw = mask[w * KHG_DEC_BLOCK];
-                    }
-                    uint32_t bit = 0x80000000u >> (rel & 31);
-                    if (mw & bit) {  // landed on a codeword start of the first run: identical from here on
-                        uint32_t rest = (uint32_t)__builtin_popcount(mw & (bit | (bit - 1)));
-                        for (uint32_t w2 = w + 1; w2 < KHG_SUB_WORDS; ++w2)
+                    uint32_t rel = pos - sub_begin;
+                    const uint32_t w = rel >> 5;
+                    const uint64_t two = ((uint64_t)mask[w * KHG_DEC_BLOCK] << 32) |
+                                         (w + 1 < KHG_SUB_WORDS ? mask[(w + 1) * KHG_DEC_BLOCK] : 0u);
+                    uint32_t r = khg_cur_runlen(cur, onebit, end - pos);
+                    // codeword starts of this run at the cursor: the run's positions, or just this one
+                    const uint64_t hits = two & khg_mask_range(rel, r ? r : 1);
+                    if (hits) {  // landed on a codeword start of the first run: identical from here on
+                        const uint32_t j = (uint32_t)__builtin_clzll(hits) - (rel & 31);
+                        n += j;
+                        rel += j;
+                        const uint32_t wq = rel >> 5, bit = 0x80000000u >> (rel & 31);
+                        uint32_t rest = (uint32_t)__builtin_popcount(mask[wq * KHG_DEC_BLOCK] & (bit | (bit - 1)));
+                        for (uint32_t w2 = wq + 1; w2 < KHG_SUB_WORDS; ++w2)
                             rest += (uint32_t)__builtin_popcount(mask[w2 * KHG_DEC_BLOCK]);
                         n += rest;
                         joined = true;
                         break;
+                    }
+                    if (r) {
+                        khg_cur_skip(cur, bits, r);
+                        pos += r;
+                        n += r;
+                        continue;
                     }
                     int s;
                     uint32_t len = khg_cur_decode(cur, bits, sh.lut, lut2, left, right, tsym, &s);
@@ -667,6 +728,7 @@ KHG_DEV void khg_dec_write_body(const KhgDecArgs& a, uint32_t blk, KhgDecSmem& s
     const int32_t* right = a.tree_right + (size_t)p * 2 * KHG_NBINS;
     const int32_t* tsym = a.tab_sym + (size_t)p * KHG_NBINS;
     const uint32_t* lut2 = a.lut2 + (size_t)p * KHG_LUT_SIZE * KHG_LUT2_SIZE;
+    const int onebit = a.hdr->one_bit[p], onesym = a.hdr->one_sym[p];
     uint32_t* s_off = sh.mask;                       // the codeword-start maps are not needed here:
     uint32_t* s_cnt = sh.mask + KHG_DEC_BLOCK;       // their space holds start offset, count and
     uint32_t* s_pre = sh.mask + 2 * KHG_DEC_BLOCK;   // count prefix of every subsequence
@@ -717,28 +779,48 @@ KHG_DEV void khg_dec_write_body(const KhgDecArgs& a, uint32_t blk, KhgDecSmem& s
             const uint32_t lim = a.n[p];
             KhgCursor cur;
             khg_cur_init(cur, bits, pos);
+            // symbols are gathered four at a time and stored as one 8-byte word where this thread owns
+            // the whole aligned group (q is 8-byte aligned at multiples of four symbols)
+            uint64_t pack = 0;
             uint32_t i = 0;
-            // single stores up to an 8-byte boundary, then four symbols per store
-            for (; i < cnt && ((o + i) & 3u); ++i) {
-                int s;
-                if (khg_cur_decode(cur, bits, sh.lut, lut2, left, right, tsym, &s) == 0) { i = cnt; break; }
-                if (o + i < lim) q[o + i] = (int16_t)s;
-            }
-            for (; i + 4 <= cnt && o + i + 4 <= lim; i += 4) {
-                uint64_t pack = 0;
-                bool dead = false;
-                for (int j = 0; j < 4; ++j) {
-                    int s;
-                    if (khg_cur_decode(cur, bits, sh.lut, lut2, left, right, tsym, &s) == 0) { dead = true; break; }
-                    pack |= (uint64_t)(uint16_t)(int16_t)s << (16 * j);
+            auto put = [&](int s) {
+                const uint32_t idx = o + i;
+                pack |= (uint64_t)(uint16_t)(int16_t)s << (16 * (idx & 3u));
+                if ((idx & 3u) == 3u || i + 1 == cnt) {
+                    const uint32_t g0 = idx & ~3u, first = g0 > o ? g0 : o;
+                    if (first == g0 && (idx & 3u) == 3u && idx < lim) {
+                        *(uint64_t*)(q + g0) = pack;
+                    } else {
+                        for (uint32_t k2 = first; k2 <= idx; ++k2)
+                            if (k2 < lim) q[k2] = (int16_t)(pack >> (16 * (k2 & 3u)));
+                    }
+                    pack = 0;
                 }
-                if (dead) { i = cnt; break; }  // cannot happen: cnt counts whole codewords
-                *(uint64_t*)(q + o + i) = pack;
-            }
-            for (; i < cnt; ++i) {
+                ++i;
+            };
+            while (i < cnt) {
+                uint32_t r = khg_cur_runlen(cur, onebit, cnt - i);
+                if (r) {  // r copies of the 1-bit code's symbol: whole aligned groups go out as constants
+                    khg_cur_skip(cur, bits, r);
+                    while (r && ((o + i) & 3u)) {
+                        put(onesym);
+                        --r;
+                    }
+                    const uint64_t z4 = 0x0001000100010001ull * (uint64_t)(uint16_t)(int16_t)onesym;
+                    while (r >= 4 && o + i + 4 <= lim) {
+                        *(uint64_t*)(q + o + i) = z4;
+                        i += 4;
+                        r -= 4;
+                    }
+                    while (r) {
+                        put(onesym);
+                        --r;
+                    }
+                    continue;
+                }
                 int s;
                 if (khg_cur_decode(cur, bits, sh.lut, lut2, left, right, tsym, &s) == 0) break;
-                if (o + i < lim) q[o + i] = (int16_t)s;
+                put(s);
             }
         }
     }
