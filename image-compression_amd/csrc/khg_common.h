@@ -25,6 +25,7 @@ static inline uint32_t khg_atomic_or(uint32_t* p, uint32_t v) { uint32_t o = *p;
 static inline int khg_atomic_max_i(int* p, int v) { int o = *p; if (v > o) *p = v; return o; }
 static inline void khg_lds_or(uint32_t* p, uint32_t v) { *p |= v; }
 static inline uint32_t khg_bswap32(uint32_t v) { return __builtin_bswap32(v); }
+static inline double khg_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 #else
 #include <hip/hip_runtime.h>
 #define KHG_DEV __device__ __forceinline__
@@ -39,6 +40,7 @@ __device__ __forceinline__ uint32_t khg_atomic_or(uint32_t* p, uint32_t v) { ret
 __device__ __forceinline__ int khg_atomic_max_i(int* p, int v) { return atomicMax(p, v); }
 __device__ __forceinline__ void khg_lds_or(uint32_t* p, uint32_t v) { atomicOr(p, v); }  // result unused: ds_or_b32, no wait
 __device__ __forceinline__ uint32_t khg_bswap32(uint32_t v) { return __builtin_bswap32(v); }
+__device__ __forceinline__ double khg_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }  // explicit: not subject to -ffp-contract
 #endif
 
 // ---------------------------------------------------------------- constants
@@ -67,6 +69,29 @@ struct KhgResult {
 KHG_DEV void khg_set_status(int* status, int code)
 {
     if (*status == 0) *status = code;  // racing writers all carry an error code: any of them will do
+}
+
+// x / c, correctly rounded, for a constant c whose correctly rounded reciprocal rc = RN(1/c) is known
+// (Markstein: q = RN(x*rc) is within an ulp, the residual x - q*c is exact in one fused multiply-add, and
+// one correction step lands on RN(x/c)).  Holds away from overflow and underflow, where every sample of
+// this codec lives; the sign of a zero quotient may differ, which no later step can observe.
+// Three instructions instead of the ~35 of an IEEE f64 division.
+KHG_DEV double khg_div_const(double x, double c, double rc)
+{
+    double q = x * rc;
+    double r = khg_fma(-q, c, x);
+    return khg_fma(r, rc, q);
+}
+
+// round(c / div) of Compress.h:218 from rdiv = RN(1/div), when that is safe: t = c*rdiv is within 2^-51
+// (relative) of the exact quotient, so both round to the same integer unless t sits that close to a
+// half-integer.  Returns false (caller must divide) for anything within 2^-40 of one.
+KHG_DEV bool khg_round_quot_fast(double c, double rdiv, double* n_out)
+{
+    double t = c * rdiv;
+    double n = trunc(t + (t < 0 ? -0.5 : 0.5));
+    *n_out = n;
+    return 0.5 - fabs(t - n) > fabs(t) * 0x1p-40;
 }
 
 // Whole-sample symmetric extension of index i onto [0, n), any i (n even, >= 2).

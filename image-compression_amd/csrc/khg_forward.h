@@ -2,9 +2,10 @@
 //
 // One workgroup (256 threads) walks down a strip of 256 columns of the plane being
 // transformed.  Per batch of 16 source rows:
-//   load   : source samples (u8 RGB -> Y / Cb / Cr in f64, or an f64 plane) -> LDS tile A
-//   rows   : each thread lifts a run of 16 outputs of one row in registers (window 24)
-//            and stores the scaled result de-interleaved (low half | high half) in LDS tile B
+//   rows   : each thread loads the 24-sample window of a run of 16 outputs of one row straight into
+//            registers (u8 RGB as packed words, converted to Y / Cb / Cr in f64, or an f64 plane), one
+//            batch ahead so the loads fly during the column phase, lifts it and stores the scaled
+//            result de-interleaved (low half | high half) in LDS tile B
 //   columns: each thread owns one column, feeds the 16 new rows through a streaming
 //            lifting pipeline held in registers, and emits finished coefficients:
 //            LL of level 1 goes to an f64 buffer, everything else is quantised to int16
@@ -17,11 +18,11 @@
 enum { KHG_SRC_Y = 0, KHG_SRC_CB = 1, KHG_SRC_CR = 2, KHG_SRC_PLANE = 3 };
 
 enum {
-    KHG_A_COLS = KHG_STRIP + 8,  // strip + 4-sample halo each side
-    KHG_A_PITCH = KHG_A_COLS + 1,  // odd pitch: conflict-free ds_read_b64 across 16 rows
-    KHG_B_PITCH = KHG_STRIP + 1,
+    KHG_B_PITCH = KHG_STRIP + 1,  // odd pitch: conflict-free ds_write_b64 across the 16 rows of a wave
     KHG_LHIST = 1024,            // LDS histogram covers symbols [-512, 511]
-    KHG_LHIST_BIAS = 512
+    KHG_LHIST_BIAS = 512,
+    KHG_MAX_SEG_ROWS = 128,      // rows per workgroup segment, at most
+    KHG_RD_N = KHG_STRIP / 2 + KHG_MAX_SEG_ROWS / 2  // reciprocal-divisor entries per band
 };
 
 struct KhgFwdArgs {
@@ -46,10 +47,10 @@ struct KhgFwdArgs {
 };
 
 struct KhgFwdSmem {
-    double A[KHG_BATCH * KHG_A_PITCH];
     double B[KHG_BATCH * KHG_B_PITCH];
     uint32_t cnt[KHG_LHIST];
     uint32_t first[KHG_LHIST];
+    double rdiv[4 * KHG_RD_N];  // 1/divisor of band slot s at diagonal u: [s * KHG_RD_N + u]
 };
 
 // Streaming state of one 1-D lifting line: values of pair j-1 (e, o, d1, s1) and d2 of pair j-2.
@@ -81,50 +82,149 @@ KHG_DEV void khg_fwd_step(KhgLift& st, double en, double on, double& s2, double&
 }
 
 // DWT.h:45-50: a = 1/1.149604398 (rounded once); odd samples x*a, even samples x/a.
-KHG_DEV double khg_fwd_scale_even(double x) { const double a = 1 / 1.149604398; return x / a; }
+KHG_DEV double khg_fwd_scale_even(double x)
+{
+    const double a = 1 / 1.149604398, ra = 1 / a;
+    return khg_div_const(x, a, ra);
+}
 KHG_DEV double khg_fwd_scale_odd(double x) { const double a = 1 / 1.149604398; return x * a; }
 
+// ---- source window of one row-phase thread: 24 consecutive samples of one row, as loaded.
+// u8 RGB sources keep the raw bytes (4 luma samples per 32-bit word; 4 chroma sites per 64-bit word, every
+// second byte) so the loads are issued a batch ahead and converted when the row phase needs them.
 template <int SRC>
-KHG_DEV double khg_fwd_load(const KhgFwdArgs& a, int gy, int gx)
+struct KhgFwdRaw {
+    uint32_t w[SRC == KHG_SRC_Y ? 18 : SRC == KHG_SRC_PLANE ? 48 : 36];
+};
+
+KHG_DEV uint32_t khg_ld32(const uint8_t* p) { return *(const uint32_t*)p; }
+
+// Row gy of the plane, samples gx0 .. gx0+23 (gx0 = 0 mod 4; columns outside [0, pw) are reflected).
+template <int SRC>
+KHG_DEV void khg_fwd_fetch(const KhgFwdArgs& a, KhgFwdRaw<SRC>& raw, int gy, int gx0)
 {
-    if (SRC == KHG_SRC_PLANE) return a.src[(size_t)gy * a.src_pitch + gx];
-    // Main.cpp:200-202 widens u8 to double; Colorspace.h:11,19,20 left-to-right products and sums.
-    size_t p = (SRC == KHG_SRC_Y) ? (size_t)gy * a.img_w + gx : (size_t)(2 * gy) * a.img_w + 2 * gx;
-    double R = (double)a.r[p], G = (double)a.g[p], B = (double)a.b[p];
-    if (SRC == KHG_SRC_Y) return R * 0.299 + G * 0.587 + B * 0.114;
+    if (SRC == KHG_SRC_PLANE) {
+        const double* row = a.src + (size_t)gy * a.src_pitch;
+        KHG_UNROLL
+        for (int k = 0; k < 12; ++k) {
+            int gx = gx0 + 2 * k;
+            double v0, v1;
+            if (gx >= 0 && gx + 1 < a.pw) {  // pw is even: a pair is inside or outside as a whole
+                v0 = row[gx];
+                v1 = row[gx + 1];
+            } else {
+                v0 = row[khg_reflect(gx, a.pw)];
+                v1 = row[khg_reflect(gx + 1, a.pw)];
+            }
+            __builtin_memcpy(&raw.w[4 * k], &v0, 8);
+            __builtin_memcpy(&raw.w[4 * k + 2], &v1, 8);
+        }
+    } else if (SRC == KHG_SRC_Y) {
+        const size_t rowoff = (size_t)gy * a.img_w;
+        KHG_UNROLL
+        for (int k = 0; k < 6; ++k) {
+            int gx = gx0 + 4 * k;
+            if (gx >= 0 && gx + 3 < a.pw) {  // pw = 0 mod 8
+                raw.w[k] = khg_ld32(a.r + rowoff + gx);
+                raw.w[6 + k] = khg_ld32(a.g + rowoff + gx);
+                raw.w[12 + k] = khg_ld32(a.b + rowoff + gx);
+            } else {
+                uint32_t r = 0, g = 0, b = 0;
+                for (int i = 0; i < 4; ++i) {
+                    size_t p = rowoff + khg_reflect(gx + i, a.pw);
+                    r |= (uint32_t)a.r[p] << (8 * i);
+                    g |= (uint32_t)a.g[p] << (8 * i);
+                    b |= (uint32_t)a.b[p] << (8 * i);
+                }
+                raw.w[k] = r; raw.w[6 + k] = g; raw.w[12 + k] = b;
+            }
+        }
+    } else {
+        // chroma site (gy, gx) reads the pixel at (2gy, 2gx): Colorspace.h:16-21
+        const size_t rowoff = (size_t)(2 * gy) * a.img_w;
+        KHG_UNROLL
+        for (int k = 0; k < 6; ++k) {
+            int gx = gx0 + 4 * k;
+            if (gx >= 0 && gx + 3 < a.pw) {  // pw = 0 mod 4
+                size_t p = rowoff + 2 * gx;
+                raw.w[2 * k] = khg_ld32(a.r + p);       raw.w[2 * k + 1] = khg_ld32(a.r + p + 4);
+                raw.w[12 + 2 * k] = khg_ld32(a.g + p);  raw.w[12 + 2 * k + 1] = khg_ld32(a.g + p + 4);
+                raw.w[24 + 2 * k] = khg_ld32(a.b + p);  raw.w[24 + 2 * k + 1] = khg_ld32(a.b + p + 4);
+            } else {
+                uint32_t r[2] = {0, 0}, g[2] = {0, 0}, b[2] = {0, 0};
+                for (int i = 0; i < 4; ++i) {
+                    size_t p = rowoff + 2 * khg_reflect(gx + i, a.pw);
+                    r[i >> 1] |= (uint32_t)a.r[p] << (16 * (i & 1));
+                    g[i >> 1] |= (uint32_t)a.g[p] << (16 * (i & 1));
+                    b[i >> 1] |= (uint32_t)a.b[p] << (16 * (i & 1));
+                }
+                raw.w[2 * k] = r[0]; raw.w[2 * k + 1] = r[1];
+                raw.w[12 + 2 * k] = g[0]; raw.w[12 + 2 * k + 1] = g[1];
+                raw.w[24 + 2 * k] = b[0]; raw.w[24 + 2 * k + 1] = b[1];
+            }
+        }
+    }
+}
+
+// Sample i (0..23) of a fetched window as the f64 value the transform runs on.
+// Main.cpp:200-202 widens u8 to double; Colorspace.h:11,19,20 left-to-right products and sums.
+template <int SRC>
+KHG_DEV double khg_fwd_sample(const KhgFwdRaw<SRC>& raw, int i)
+{
+    if (SRC == KHG_SRC_PLANE) {
+        double v;
+        __builtin_memcpy(&v, &raw.w[2 * i], 8);
+        return v;
+    }
+    double R, G, B;
+    if (SRC == KHG_SRC_Y) {
+        int k = i >> 2, sh = 8 * (i & 3);
+        R = (double)((raw.w[k] >> sh) & 255u);
+        G = (double)((raw.w[6 + k] >> sh) & 255u);
+        B = (double)((raw.w[12 + k] >> sh) & 255u);
+        return R * 0.299 + G * 0.587 + B * 0.114;
+    }
+    int k = i >> 1, sh = 16 * (i & 1);
+    R = (double)((raw.w[k] >> sh) & 255u);
+    G = (double)((raw.w[12 + k] >> sh) & 255u);
+    B = (double)((raw.w[24 + k] >> sh) & 255u);
     if (SRC == KHG_SRC_CB) return R * -0.16874 + G * -0.33126 + B * 0.5;
     return R * 0.5 + G * -0.41869 + B * -0.08131;
 }
 
-// Per-thread counts and first raster indices of the symbols -1, 0, +1.  These make up almost all
-// detail-band symbols; counting them in registers keeps 64 lanes from hammering one LDS word.
+// Per-thread tally of the symbols -1, 0, +1, which make up almost all detail-band symbols: counting them
+// in registers keeps 64 lanes from hammering one LDS word.  cnt packs three 21-bit counters (a thread
+// emits far fewer symbols per segment); seen has one bit per (symbol, output stream).  A thread's raster
+// indices rise within each of its two output streams (rows k and rows hh+k), so only the first hit of a
+// symbol in a stream can lower the workgroup's first-appearance index: one LDS atomic per bit, ever.
 struct KhgHot {
-    uint32_t cm, c0, cp;
-    uint32_t fm, f0, fp;
+    uint64_t cnt;
+    uint32_t seen;
 };
 
 // Quantise one coefficient, store the symbol and count it (Compress.h:218-219, Huffman.h:110-139).
-KHG_DEV void khg_quant_store(const KhgFwdArgs& a, KhgFwdSmem& sh, KhgHot& hot, double c, int band, int y, int x)
+// rdiv = RN(1/divisor) of this position (khg_round_quot_fast); stream 0 = rows k, 1 = rows hh+k.
+KHG_DEV void khg_quant_store(const KhgFwdArgs& a, KhgFwdSmem& sh, KhgHot& hot, double c, double rdiv, int band,
+                             int stream, int y, int x)
 {
-    double div = khg_divisor(a.q, band, x, y, a.lvl);
-    int q = (int)round(c / div);
-    if (q < -KHG_SYM_BIAS || q >= KHG_SYM_BIAS) {
+    double n;
+    if (!khg_round_quot_fast(c, rdiv, &n)) n = round(c / khg_divisor(a.q, band, x, y, a.lvl));
+    if (!(n >= -(double)KHG_SYM_BIAS && n < (double)KHG_SYM_BIAS)) {
         khg_set_status(a.status, -4);
-        q = 0;
+        n = 0;
     }
+    int q = (int)n;
     uint32_t raster = (uint32_t)y * (uint32_t)a.sym_pitch + (uint32_t)x;
     a.sym[raster] = (int16_t)q;
-    if ((unsigned)(q + 1) <= 2u) {
-        hot.cm += q == -1;
-        hot.c0 += q == 0;
-        hot.cp += q == 1;
-        hot.fm = (q == -1 && raster < hot.fm) ? raster : hot.fm;
-        hot.f0 = (q == 0 && raster < hot.f0) ? raster : hot.f0;
-        hot.fp = (q == 1 && raster < hot.fp) ? raster : hot.fp;
-        return;
-    }
     int l = q + KHG_LHIST_BIAS;
-    if ((unsigned)l < (unsigned)KHG_LHIST) {
+    if ((unsigned)(q + 1) <= 2u) {
+        hot.cnt += 1ull << (21 * (q + 1));
+        uint32_t bit = 1u << (2 * (q + 1) + stream);
+        if (!(hot.seen & bit)) {
+            hot.seen |= bit;
+            khg_atomic_min(&sh.first[l], raster);
+        }
+    } else if ((unsigned)l < (unsigned)KHG_LHIST) {
         khg_atomic_add(&sh.cnt[l], 1u);
         khg_atomic_min(&sh.first[l], raster);
     } else {
@@ -148,113 +248,110 @@ KHG_DEV void khg_fwd_strip_body(const KhgFwdArgs& a, int bid, KhgFwdSmem& sh)
 
     KhgLift cs[KHG_NSLOT(256)];
     KhgHot hots[KHG_NSLOT(256)];
+    KhgFwdRaw<SRC> raws[KHG_NSLOT(256)];
     KHG_FOR_THREADS(256)
     {
         KhgLift z = {0, 0, 0, 0, 0};
         cs[KHG_SLOT] = z;
-        KhgHot hz = {0, 0, 0, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+        KhgHot hz = {0, 0};
         hots[KHG_SLOT] = hz;
+        // window of the first batch (row-phase mapping: row tid & 15, run tid >> 4)
+        khg_fwd_fetch<SRC>(a, raws[KHG_SLOT], khg_reflect(rin0 + (tid & 15), a.ph), x0 + (tid >> 4) * 16 - 4);
         for (int i = tid; i < KHG_LHIST; i += 256) {
             sh.cnt[i] = 0;
             sh.first[i] = 0xFFFFFFFFu;
         }
+        // The divisor depends on the band and on x + y only (Compress.h:215-218); column c of the strip at
+        // row pair k sits on diagonal u = c/2 + (k - k0) of each band this workgroup emits.
+        const int nu = KHG_STRIP / 2 + (k1 - k0);
+        for (int e = tid; e < 4 * nu; e += 256) {
+            int s = e / nu, u = e - s * nu;
+            int band = LEVEL == 1 ? 4 + s : s;
+            if (band > 6) break;
+            int by = (LEVEL == 1 ? (band >= 5) : (band >= 2)) ? hh : 0;
+            int bx = (LEVEL == 1 ? (band != 5) : (band & 1)) ? hw : 0;
+            sh.rdiv[s * KHG_RD_N + u] = 1.0 / khg_divisor(a.q, band, bx + (x0 >> 1) + u, by + k0, a.lvl);
+        }
     }
     KHG_BARRIER();
 
-    for (int b = 0; b <= nb; ++b) {
+    for (int b = 0; b < nb; ++b) {
         KHG_FOR_THREADS(256)
         {
-            if (b > 0) {
-                // ---- column phase of batch b-1: thread tid owns de-interleaved column tid
-                const int half = tid >> 7, tt = tid & 127;
-                const int c = 2 * tt + half;  // strip-local source column
-                const bool colok = x0 + c < a.pw;
-                const int xq = (x0 >> 1) + tt;
-                const int xo = half ? hw + xq : xq;  // packed output column
-                KhgLift st = cs[KHG_SLOT];
-                KhgHot hot = hots[KHG_SLOT];
-                for (int rr = 0; rr < KHG_BATCH; rr += 2) {
-                    double en = sh.B[rr * KHG_B_PITCH + tid];
-                    double on = sh.B[(rr + 1) * KHG_B_PITCH + tid];
-                    double s2, d2;
-                    khg_fwd_step(st, en, on, s2, d2);
-                    int k = (rin0 + (b - 1) * KHG_BATCH + rr) / 2 - 2;  // numerator is even
-                    if (colok && k >= k0 && k < k1) {
-                        double lo = khg_fwd_scale_even(s2), hi = khg_fwd_scale_odd(d2);
-                        if (a.coef) {
-                            a.coef[(size_t)k * a.coef_pitch + xo] = lo;
-                            a.coef[(size_t)(hh + k) * a.coef_pitch + xo] = hi;
-                        }
-                        if (LEVEL == 1) {
-                            if (half == 0) {
-                                a.ll[(size_t)k * a.ll_pitch + xq] = lo;
-                                khg_quant_store(a, sh, hot, hi, 5, hh + k, xo);
-                            } else {
-                                khg_quant_store(a, sh, hot, lo, 4, k, xo);
-                                khg_quant_store(a, sh, hot, hi, 6, hh + k, xo);
-                            }
-                        } else {
-                            if (half == 0) {
-                                khg_quant_store(a, sh, hot, lo, 0, k, xo);
-                                khg_quant_store(a, sh, hot, hi, 2, hh + k, xo);
-                            } else {
-                                khg_quant_store(a, sh, hot, lo, 1, k, xo);
-                                khg_quant_store(a, sh, hot, hi, 3, hh + k, xo);
-                            }
-                        }
-                    }
-                }
-                cs[KHG_SLOT] = st;
-                hots[KHG_SLOT] = hot;
-            }
-            if (b < nb) {
-                // ---- load phase of batch b
-                for (int e = tid; e < KHG_BATCH * KHG_A_COLS; e += 256) {
-                    int rr = e / KHG_A_COLS, i = e - rr * KHG_A_COLS;
-                    int gy = khg_reflect(rin0 + b * KHG_BATCH + rr, a.ph);
-                    int gx = khg_reflect(x0 - 4 + i, a.pw);
-                    sh.A[rr * KHG_A_PITCH + i] = khg_fwd_load<SRC>(a, gy, gx);
+            // ---- row phase: row rr of the batch, outputs [16*run, 16*run+16) of the strip
+            const int rr = tid & 15, run = tid >> 4;
+            KhgFwdRaw<SRC>& raw = raws[KHG_SLOT];
+            double* blo = &sh.B[rr * KHG_B_PITCH + run * 8];
+            double* bhi = blo + 128;
+            KhgLift st = {0, 0, 0, 0, 0};
+            KHG_UNROLL
+            for (int j = 0; j < 12; ++j) {
+                double s2, d2;
+                khg_fwd_step(st, khg_fwd_sample<SRC>(raw, 2 * j), khg_fwd_sample<SRC>(raw, 2 * j + 1), s2, d2);
+                if (j >= 4) {
+                    blo[j - 4] = khg_fwd_scale_even(s2);
+                    bhi[j - 4] = khg_fwd_scale_odd(d2);
                 }
             }
+            // next batch's window: in flight while the column phase runs
+            if (b + 1 < nb)
+                khg_fwd_fetch<SRC>(a, raw, khg_reflect(rin0 + (b + 1) * KHG_BATCH + rr, a.ph), x0 + run * 16 - 4);
         }
         KHG_BARRIER();
-        if (b < nb) {
-            KHG_FOR_THREADS(256)
-            {
-                // ---- row phase: row rr, outputs [16*run, 16*run+16) of the strip
-                const int rr = tid & 15, run = tid >> 4;
-                const double* w = &sh.A[rr * KHG_A_PITCH + run * 16];
-                double* blo = &sh.B[rr * KHG_B_PITCH + run * 8];
-                double* bhi = blo + 128;
-                KhgLift st = {0, 0, 0, 0, 0};
-KHG_UNROLL
-                for (int j = 0; j < 12; ++j) {
-                    double s2, d2;
-                    khg_fwd_step(st, w[2 * j], w[2 * j + 1], s2, d2);
-                    if (j >= 4) {
-                        blo[j - 4] = khg_fwd_scale_even(s2);
-                        bhi[j - 4] = khg_fwd_scale_odd(d2);
+        KHG_FOR_THREADS(256)
+        {
+            // ---- column phase: thread tid owns de-interleaved column tid
+            const int half = tid >> 7, tt = tid & 127;
+            const int c = 2 * tt + half;  // strip-local source column
+            const bool colok = x0 + c < a.pw;
+            const int xq = (x0 >> 1) + tt;
+            const int xo = half ? hw + xq : xq;  // packed output column
+            KhgLift st = cs[KHG_SLOT];
+            KhgHot hot = hots[KHG_SLOT];
+            for (int rr = 0; rr < KHG_BATCH; rr += 2) {
+                double en = sh.B[rr * KHG_B_PITCH + tid];
+                double on = sh.B[(rr + 1) * KHG_B_PITCH + tid];
+                double s2, d2;
+                khg_fwd_step(st, en, on, s2, d2);
+                int k = (rin0 + b * KHG_BATCH + rr) / 2 - 2;  // numerator is even
+                if (colok && k >= k0 && k < k1) {
+                    const double* rd = &sh.rdiv[tt + (k - k0)];
+                    double lo = khg_fwd_scale_even(s2), hi = khg_fwd_scale_odd(d2);
+                    if (a.coef) {
+                        a.coef[(size_t)k * a.coef_pitch + xo] = lo;
+                        a.coef[(size_t)(hh + k) * a.coef_pitch + xo] = hi;
+                    }
+                    if (LEVEL == 1) {
+                        if (half == 0) {
+                            a.ll[(size_t)k * a.ll_pitch + xq] = lo;
+                            khg_quant_store(a, sh, hot, hi, rd[1 * KHG_RD_N], 5, 1, hh + k, xo);
+                        } else {
+                            khg_quant_store(a, sh, hot, lo, rd[0 * KHG_RD_N], 4, 0, k, xo);
+                            khg_quant_store(a, sh, hot, hi, rd[2 * KHG_RD_N], 6, 1, hh + k, xo);
+                        }
+                    } else {
+                        if (half == 0) {
+                            khg_quant_store(a, sh, hot, lo, rd[0 * KHG_RD_N], 0, 0, k, xo);
+                            khg_quant_store(a, sh, hot, hi, rd[2 * KHG_RD_N], 2, 1, hh + k, xo);
+                        } else {
+                            khg_quant_store(a, sh, hot, lo, rd[1 * KHG_RD_N], 1, 0, k, xo);
+                            khg_quant_store(a, sh, hot, hi, rd[3 * KHG_RD_N], 3, 1, hh + k, xo);
+                        }
                     }
                 }
             }
-            KHG_BARRIER();
+            cs[KHG_SLOT] = st;
+            hots[KHG_SLOT] = hot;
         }
+        KHG_BARRIER();
     }
 
     KHG_FOR_THREADS(256)
     {
         const KhgHot hot = hots[KHG_SLOT];
-        if (hot.cm) {
-            khg_atomic_add(&sh.cnt[KHG_LHIST_BIAS - 1], hot.cm);
-            khg_atomic_min(&sh.first[KHG_LHIST_BIAS - 1], hot.fm);
-        }
-        if (hot.c0) {
-            khg_atomic_add(&sh.cnt[KHG_LHIST_BIAS], hot.c0);
-            khg_atomic_min(&sh.first[KHG_LHIST_BIAS], hot.f0);
-        }
-        if (hot.cp) {
-            khg_atomic_add(&sh.cnt[KHG_LHIST_BIAS + 1], hot.cp);
-            khg_atomic_min(&sh.first[KHG_LHIST_BIAS + 1], hot.fp);
+        for (int v = 0; v < 3; ++v) {
+            uint32_t c = (uint32_t)(hot.cnt >> (21 * v)) & 0x1FFFFFu;
+            if (c) khg_atomic_add(&sh.cnt[KHG_LHIST_BIAS - 1 + v], c);
         }
     }
     KHG_BARRIER();

@@ -55,7 +55,8 @@ KHG_DEV void khg_inv_step(KhgILift& st, double lo, double hi, double& xe, double
 {
     const double A = 1.149604398;
     const double C1 = -0.4435068522, C2 = -0.8829110762, C3 = 0.05298011854, C4 = 1.586134342;
-    double sn = lo / A, dn = hi * A;
+    const double rA = 1 / A;
+    double sn = khg_div_const(lo, A, rA), dn = hi * A;
     double s1n = sn + C1 * (st.d + dn);
     double d1n = st.d + C2 * (st.s1 + s1n);
     double s0n = st.s1 + C3 * (st.d1 + d1n);

@@ -97,6 +97,8 @@ static inline KhgFwdGrid khg_fwd_grid(int ph, int pw)
     int nseg = 1024 / g.nstrip;            // aim for ~1024 workgroups on large planes
     int maxseg = ph / 32 > 0 ? ph / 32 : 1; // but keep >= 32 rows per segment (8 warm-up rows each)
     if (nseg > maxseg) nseg = maxseg;
+    int minseg = (ph + KHG_MAX_SEG_ROWS - 1) / KHG_MAX_SEG_ROWS;  // the kernels size LDS tables by this cap
+    if (nseg < minseg) nseg = minseg;
     if (nseg < 1) nseg = 1;
     int seg = (ph + nseg - 1) / nseg;
     seg = (seg + 1) & ~1;

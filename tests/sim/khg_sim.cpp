@@ -179,4 +179,23 @@ void khgsim_synth(uint8_t* r, uint8_t* g, uint8_t* b, int rows, int cols, uint32
         }
 }
 
+// Arithmetic shortcuts against the operations they replace: out_div[i] = khg_div_const(x[i], c, 1/c),
+// out_round[i] = the quantiser's rounding of x[i] / d[i]; fast[i] = 1 when no division was needed.
+void khgsim_div_const(const double* x, size_t n, double c, double* out_div)
+{
+    const double rc = 1 / c;
+    for (size_t i = 0; i < n; ++i) out_div[i] = khg_div_const(x[i], c, rc);
+}
+
+void khgsim_round_quot(const double* x, const double* d, size_t n, double* out_round, uint8_t* fast)
+{
+    for (size_t i = 0; i < n; ++i) {
+        double r;
+        bool ok = khg_round_quot_fast(x[i], 1.0 / d[i], &r);
+        if (!ok) r = round(x[i] / d[i]);
+        out_round[i] = r;
+        fast[i] = ok;
+    }
+}
+
 }  // extern "C"

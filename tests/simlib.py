@@ -36,6 +36,11 @@ def lib():
         L.khgsim_ssim.restype = C.c_double
         L.khgsim_synth.argtypes = [_u8p, _u8p, _u8p, C.c_int, C.c_int, C.c_uint32, C.c_uint32]
         L.khgsim_synth.restype = None
+        _f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+        L.khgsim_div_const.argtypes = [_f64p, C.c_size_t, C.c_double, _f64p]
+        L.khgsim_div_const.restype = None
+        L.khgsim_round_quot.argtypes = [_f64p, _f64p, C.c_size_t, _f64p, _u8p]
+        L.khgsim_round_quot.restype = None
         _lib = L
     return _lib
 
@@ -78,3 +83,17 @@ def synth(rows, cols, seed, index):
     out = np.zeros((3, rows, cols), np.uint8)
     lib().khgsim_synth(out[0], out[1], out[2], rows, cols, seed, index)
     return out
+
+
+def div_const(x, c):
+    x = np.ascontiguousarray(x, np.float64)
+    out = np.empty_like(x)
+    lib().khgsim_div_const(x, x.size, c, out)
+    return out
+
+
+def round_quot(x, d):
+    x = np.ascontiguousarray(x, np.float64); d = np.ascontiguousarray(d, np.float64)
+    out = np.empty_like(x); fast = np.empty(x.size, np.uint8)
+    lib().khgsim_round_quot(x, d, x.size, out, fast)
+    return out, fast

@@ -88,3 +88,47 @@ def test_output_capacity_is_checked():
 def test_device_synth_twin():
     for (h, w, seed, idx) in [(16, 24, 2025, 0), (136, 264, 2025, 77)]:
         assert np.array_equal(S.synth(h, w, seed, idx), synth_frame(h, w, seed, idx))
+
+
+def _random_doubles(rng, n):
+    """Signed doubles over 120 binades with random mantissas, plus values with few mantissa bits."""
+    m = rng.integers(0, 1 << 52, n, dtype=np.uint64)
+    m[: n // 4] &= ~np.uint64((1 << 40) - 1)  # short mantissas: products and residuals with long runs of zeros
+    e = rng.integers(1023 - 60, 1023 + 60, n, dtype=np.uint64)
+    s = rng.integers(0, 2, n, dtype=np.uint64)
+    return ((s << np.uint64(63)) | (e << np.uint64(52)) | m).view(np.float64)
+
+
+def test_division_by_the_scale_constant_is_exact():
+    """khg_div_const must equal IEEE division for the two constants the lifting scale step divides by
+    (DWT.h:45-50 forward, DWT.h:76-82 inverse)."""
+    rng = np.random.default_rng(7)
+    a = 1 / 1.149604398
+    for c in (a, 1.149604398):
+        for _ in range(8):
+            x = _random_doubles(rng, 1 << 21)
+            assert np.array_equal(S.div_const(x, c), x / c)
+        x = np.concatenate([np.arange(-4096, 4096, dtype=np.float64), np.arange(-4096, 4096) * c,
+                            np.nextafter(np.arange(1, 4096) * c, np.inf), np.nextafter(np.arange(1, 4096) * c, -np.inf)])
+        assert np.array_equal(S.div_const(x, c), x / c)
+
+
+def test_quantiser_rounding_shortcut():
+    """round(c/div) through the reciprocal: equal to the division everywhere, including quotients on and
+    next to half-integers, where the shortcut must hand over to the division."""
+    rng = np.random.default_rng(8)
+    d = rng.uniform(0.05, 900.0, 1 << 20)
+    k = rng.integers(-8000, 8000, d.size).astype(np.float64)
+    half = (k + 0.5) * d
+    cases = [rng.uniform(-8000, 8000, d.size) * d, half, np.nextafter(half, np.inf), np.nextafter(half, -np.inf),
+             half * (1 + 2.0 ** -44), half * (1 - 2.0 ** -44), k * d, np.zeros_like(d)]
+    for c in cases:
+        q = c / d
+        tr = np.trunc(q)
+        want = tr + np.sign(q) * (np.abs(q - tr) >= 0.5)  # std::round: halves away from zero
+        got, fast = S.round_quot(c, d)
+        assert np.array_equal(got, want)
+    got, fast = S.round_quot(cases[0], d)
+    assert fast.mean() > 0.999  # the division is the rare path
+    got, fast = S.round_quot(half, d)
+    assert fast.sum() == 0
