@@ -99,7 +99,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--frames", type=int, default=128, help="frames per GPU per step")
-    ap.add_argument("--streams", type=int, default=4, help="contexts/streams in flight per GPU")
+    ap.add_argument("--streams", type=int, default=8, help="contexts/streams in flight per GPU")
     ap.add_argument("--rows", type=int, default=ROWS)
     ap.add_argument("--cols", type=int, default=COLS)
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -39,17 +39,7 @@ static inline KhgDecArgs khg_dec_args(const KhgWorkspace& ws, const KhgDecWorksp
 // Grid of one inverse-transform launch over a ph x pw plane.
 static inline KhgFwdGrid khg_inv_grid(int ph, int pw)
 {
-    KhgFwdGrid g;
-    g.nstrip = (pw + KHG_ISTRIP - 1) / KHG_ISTRIP;
-    int nseg = 1024 / g.nstrip;
-    int maxseg = ph / 32 > 0 ? ph / 32 : 1;
-    if (nseg > maxseg) nseg = maxseg;
-    if (nseg < 1) nseg = 1;
-    int seg = (ph + nseg - 1) / nseg;
-    seg = (seg + 1) & ~1;
-    g.seg_rows = seg;
-    g.nseg = (ph + seg - 1) / seg;
-    return g;
+    return khg_strip_grid(ph, (pw + KHG_ISTRIP - 1) / KHG_ISTRIP, 1280, 8, 512);  // 5 workgroups per CU
 }
 
 // Inverse-transform arguments of colour component comp at level 2 (into the LL buffer) or

@@ -180,29 +180,68 @@ KHG_DEV void khg_dec_header_body(const KhgDecArgs& a)
     }
 }
 
+enum { KHG_FILL_LIST = 160 };  // LUT spans of 64+ entries are filled by the whole workgroup; a tree has at most 126
+
 struct KhgDecTreeSmem {
     alignas(16) uint32_t w[6 * KHG_TREE_LDS_K + 8];
     int32_t root;
     int maxlen;
-    uint32_t nmiss;
+    uint32_t nfill;
+    uint32_t fill_at[KHG_FILL_LIST], fill_n[KHG_FILL_LIST], fill_e[KHG_FILL_LIST];
 };
 
-// Depth of a leaf = length of its code (Huffman.h:57-68).
-KHG_DEV int khg_leaf_depth(const uint32_t* parent, int leaf, int root)
+// Depth of a node and the bits of the path from the root to it, first edge most significant (Huffman.h:57-68).
+KHG_DEV int khg_node_path(const uint32_t* parent, int node, int root, uint64_t* code_out)
 {
-    int len = 0, node = leaf;
+    int len = 0;
+    uint64_t code = 0;
     while (node != root) {
-        node = (int)(parent[node] & 0x7FFFFFFFu);
+        uint32_t p = parent[node];
+        if (len < 64) code |= (uint64_t)(p >> 31) << len;
+        node = (int)(p & 0x7FFFFFFFu);
         ++len;
     }
+    *code_out = code;
     return len;
 }
 
+// Decode-table entries of tree node `node` (leaf when node < k): every first-level slot whose
+// KHG_LUT_BITS-bit prefix decides on this node, and likewise one level down.
+//   leaf, depth d <= 12         : lut[code << (12-d) ...] x 2^(12-d)
+//   internal node, depth 12     : lut[code] = node
+//   leaf, 12 < d <= 20          : lut2[prefix][rest << (20-d) ...] x 2^(20-d)
+//   internal node, depth 20     : lut2[prefix][rest] = node
+// Spans of 64 entries or more are queued for the whole workgroup.
+KHG_DEV void khg_lut_scatter(KhgDecTreeSmem& sh, uint32_t* lut, uint32_t* lut2, int node, int k, int d, uint64_t code,
+                             int sym)
+{
+    const bool leaf = node < k;
+    const uint32_t e = leaf ? 0x80000000u | ((uint32_t)d << 16) | (uint32_t)(uint16_t)(int16_t)sym : (uint32_t)node;
+    if (d <= KHG_LUT_BITS) {
+        if (!leaf && d != KHG_LUT_BITS) return;
+        const uint32_t n = 1u << (KHG_LUT_BITS - d), at = (uint32_t)code << (KHG_LUT_BITS - d);
+        if (n >= 64) {
+            uint32_t i = khg_atomic_add(&sh.nfill, 1u);
+            sh.fill_at[i] = at; sh.fill_n[i] = n; sh.fill_e[i] = e;
+        } else {
+            for (uint32_t j = 0; j < n; ++j) lut[at + j] = e;
+        }
+    } else if (d <= KHG_LUT_BITS + KHG_LUT2_BITS) {
+        if (!leaf && d != KHG_LUT_BITS + KHG_LUT2_BITS) return;
+        const int r = d - KHG_LUT_BITS;  // bits below the first-level prefix
+        const uint32_t v = (uint32_t)(code >> r), rest = (uint32_t)code & ((1u << r) - 1);
+        const uint32_t n = 1u << (KHG_LUT2_BITS - r);
+        uint32_t* row = lut2 + (size_t)v * KHG_LUT2_SIZE + (rest << (KHG_LUT2_BITS - r));
+        for (uint32_t j = 0; j < n; ++j) row[j] = e;
+    }
+}
+
 // bid = colour component.  Rebuilds the tree from the stored table with the encoder's own
-// construction (Decompress.h:45-47), finds the longest code and fills the first-level decode table.
+// construction (Decompress.h:45-47), finds the longest code and fills the decode tables.
 // LUT entry: bit 31 set = leaf reached: bits 16..23 code length, bits 0..15 symbol (int16);
 // otherwise the entry is the node reached after KHG_LUT_BITS bits (first level) or after
-// KHG_LUT_BITS + KHG_LUT2_BITS bits (second level, one 256-entry table per missing 12-bit prefix).
+// KHG_LUT_BITS + KHG_LUT2_BITS bits (second level, one 256-entry table per 12-bit prefix that
+// ends on an internal node; rows of other prefixes are never read and stay unwritten).
 KHG_DEV void khg_dec_tree_body(const KhgDecArgs& a, int bid, KhgDecTreeSmem& sh)
 {
     KhgDecHeader* h = a.hdr;
@@ -213,7 +252,14 @@ KHG_DEV void khg_dec_tree_body(const KhgDecArgs& a, int bid, KhgDecTreeSmem& sh)
     int32_t* left = a.tree_left + (size_t)bid * 2 * KHG_NBINS;
     int32_t* right = a.tree_right + (size_t)bid * 2 * KHG_NBINS;
     uint32_t* lut = a.lut + (size_t)bid * KHG_LUT_SIZE;
+    uint32_t* lut2 = a.lut2 + (size_t)bid * KHG_LUT_SIZE * KHG_LUT2_SIZE;
     const uint8_t* tb = a.comp + h->table_byte[bid];
+    const bool in_lds = k <= KHG_TREE_LDS_K;  // heap arrays in LDS, else in global scratch
+    uint32_t* g = a.big_scratch + (size_t)bid * 10 * KHG_NBINS;
+    uint32_t* nfreq_l = sh.w + 2 * KHG_TREE_LDS_K + 4;
+    uint32_t* parent_l = sh.w + 4 * KHG_TREE_LDS_K + 4;
+    uint32_t* nfreq_g = g + 2 * KHG_NBINS + 4;
+    uint32_t* parent_g = g + 4 * KHG_NBINS + 4;
 
     KHG_FOR_THREADS(256)
     {
@@ -222,19 +268,23 @@ KHG_DEV void khg_dec_tree_body(const KhgDecArgs& a, int bid, KhgDecTreeSmem& sh)
             tcnt[i] = cnt;
             tsym[i] = s;
             if (s < -32768 || s > 32767) khg_set_status(&a.res->status, -4);
+            if (in_lds) nfreq_l[i] = (uint32_t)cnt;
+            else nfreq_g[i] = (uint32_t)cnt;
+            left[i] = -1;
+            right[i] = -1;
         }
         if (tid == 0) {
             sh.maxlen = 0;
-            sh.nmiss = 0;
+            sh.nfill = 0;
         }
     }
     KHG_BARRIER();
-    if (k <= KHG_TREE_LDS_K) {  // separate copies: LDS vs global address space of the heap arrays
-        uint32_t* parent = sh.w + 4 * KHG_TREE_LDS_K + 4;
+    // separate copies of the sequential part and of the node walk: LDS vs global address space
+    if (in_lds) {
         KHG_FOR_THREADS(256)
         {
             if (tid == 0) {
-                sh.root = khg_tree_build(tcnt, k, (uint64_t*)sh.w + 1, sh.w + 2 * KHG_TREE_LDS_K + 4, parent, left, right);
+                sh.root = khg_tree_build(k, (uint64_t*)sh.w + 1, nfreq_l, parent_l, left, right);
                 a.tree_root[bid] = sh.root;
             }
         }
@@ -242,19 +292,19 @@ KHG_DEV void khg_dec_tree_body(const KhgDecArgs& a, int bid, KhgDecTreeSmem& sh)
         KHG_FOR_THREADS(256)
         {
             int m = 0;
-            for (int i = tid; i < k; i += 256) {
-                int d = khg_leaf_depth(parent, i, sh.root);
-                m = d > m ? d : m;
+            for (int node = tid; node < 2 * k - 1; node += 256) {
+                uint64_t code;
+                int d = khg_node_path(parent_l, node, sh.root, &code);
+                if (node < k && d > m) m = d;
+                khg_lut_scatter(sh, lut, lut2, node, k, d, code, node < k ? tsym[node] : 0);
             }
             if (m) khg_atomic_max_i(&sh.maxlen, m);
         }
     } else {
-        uint32_t* g = a.big_scratch + (size_t)bid * 10 * KHG_NBINS;
-        uint32_t* parent = g + 4 * KHG_NBINS + 4;
         KHG_FOR_THREADS(256)
         {
             if (tid == 0) {
-                sh.root = khg_tree_build(tcnt, k, (uint64_t*)g + 1, g + 2 * KHG_NBINS + 4, parent, left, right);
+                sh.root = khg_tree_build(k, (uint64_t*)g + 1, nfreq_g, parent_g, left, right);
                 a.tree_root[bid] = sh.root;
             }
         }
@@ -262,9 +312,11 @@ KHG_DEV void khg_dec_tree_body(const KhgDecArgs& a, int bid, KhgDecTreeSmem& sh)
         KHG_FOR_THREADS(256)
         {
             int m = 0;
-            for (int i = tid; i < k; i += 256) {
-                int d = khg_leaf_depth(parent, i, sh.root);
-                m = d > m ? d : m;
+            for (int node = tid; node < 2 * k - 1; node += 256) {
+                uint64_t code;
+                int d = khg_node_path(parent_g, node, sh.root, &code);
+                if (node < k && d > m) m = d;
+                khg_lut_scatter(sh, lut, lut2, node, k, d, code, node < k ? tsym[node] : 0);
             }
             if (m) khg_atomic_max_i(&sh.maxlen, m);
         }
@@ -284,42 +336,9 @@ KHG_DEV void khg_dec_tree_body(const KhgDecArgs& a, int bid, KhgDecTreeSmem& sh)
             h->one_sym[bid] = os;
             if (sh.maxlen > KHG_MAX_CODE_BITS) khg_set_status(&a.res->status, -4);
         }
-        for (int v = tid; v < KHG_LUT_SIZE; v += 256) {
-            int node = root, d = 0;
-            uint32_t e;
-            if (k == 1) {
-                e = 0x80000000u;  // never consulted: a single-entry plane has no bits
-            } else {
-                while (d < KHG_LUT_BITS && left[node] >= 0) {
-                    node = ((v >> (KHG_LUT_BITS - 1 - d)) & 1) ? right[node] : left[node];
-                    ++d;
-                }
-                if (left[node] < 0) e = 0x80000000u | ((uint32_t)d << 16) | (uint32_t)(uint16_t)(int16_t)tsym[node];
-                else {
-                    e = (uint32_t)node;
-                    sh.w[khg_atomic_add(&sh.nmiss, 1u)] = (uint32_t)v;  // the heap arrays are dead by now
-                }
-            }
-            lut[v] = e;
-        }
-    }
-    KHG_BARRIER();
-    KHG_FOR_THREADS(256)
-    {
-        // second level: 8 more bits below every missing prefix
-        uint32_t* lut2 = a.lut2 + (size_t)bid * KHG_LUT_SIZE * KHG_LUT2_SIZE;
-        const uint32_t total = sh.nmiss * KHG_LUT2_SIZE;
-        for (uint32_t j = (uint32_t)tid; j < total; j += 256) {
-            const uint32_t v = sh.w[j / KHG_LUT2_SIZE], x = j % KHG_LUT2_SIZE;
-            int node = (int)lut[v], d = 0;
-            while (d < KHG_LUT2_BITS && left[node] >= 0) {
-                node = ((x >> (KHG_LUT2_BITS - 1 - d)) & 1) ? right[node] : left[node];
-                ++d;
-            }
-            uint32_t e;
-            if (left[node] < 0) e = 0x80000000u | ((uint32_t)(KHG_LUT_BITS + d) << 16) | (uint32_t)(uint16_t)(int16_t)tsym[node];
-            else e = (uint32_t)node;
-            lut2[(size_t)v * KHG_LUT2_SIZE + x] = e;
+        for (uint32_t f = 0; f < sh.nfill; ++f) {
+            const uint32_t at = sh.fill_at[f], n = sh.fill_n[f], e = sh.fill_e[f];
+            for (uint32_t j = (uint32_t)tid; j < n; j += 256) lut[at + j] = e;
         }
     }
 }

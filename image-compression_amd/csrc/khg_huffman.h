@@ -69,9 +69,31 @@ KHG_DEV uint64_t khg_heap_pop(uint64_t* heap, int& n)
         uint64_t value = heap[len];
         heap[len] = top;
         int hole = 0, child = 0;
-        while (child < (len - 1) / 2) {
+        // heap[] starts 8 bytes past a 16-byte boundary, so the sibling pair (2i+1, 2i+2) is one aligned 16-byte load
+        const int lim = (len - 1) / 2;
+        // two levels per memory round trip while both are complete: the children of `child` and the
+        // children of both of them are fetched together, then the two picks are made from registers
+        while (2 * child + 2 < lim) {
+            const int c2 = 2 * (child + 1);
+            const KhgPair pr = *(const KhgPair*)&heap[c2 - 1];
+            const KhgPair ga = *(const KhgPair*)&heap[2 * c2 - 1];  // children of c2 - 1
+            const KhgPair gb = *(const KhgPair*)&heap[2 * c2 + 1];  // children of c2
+            const bool la = khg_heap_comp(pr.b, pr.a);              // step 1 takes the left sibling
+            const uint64_t pick = la ? pr.a : pr.b;
+            const KhgPair g = la ? ga : gb;
+            int c4 = 2 * ((la ? c2 - 1 : c2) + 1);
+            uint64_t pick2 = g.b;
+            if (khg_heap_comp(g.b, g.a)) {
+                c4--;
+                pick2 = g.a;
+            }
+            heap[hole] = pick;
+            heap[la ? c2 - 1 : c2] = pick2;
+            hole = c4;
+            child = c4;
+        }
+        while (child < lim) {
             child = 2 * (child + 1);
-            // heap[] starts 8 bytes past a 16-byte boundary, so the pair (child-1, child) is one aligned 16-byte load
             const KhgPair pr = *(const KhgPair*)&heap[child - 1];
             uint64_t pick = pr.b;
             if (khg_heap_comp(pr.b, pr.a)) {
@@ -93,19 +115,22 @@ KHG_DEV uint64_t khg_heap_pop(uint64_t* heap, int& n)
 }
 
 // One thread.  Leaves are nodes 0..k-1 in table order; internal nodes k..2k-2 in creation order.
+// On entry nfreq[0..k) holds the table counts and left/right[0..k) are already -1 (both filled by all
+// threads beforehand, so this sequential part touches global memory with stores only).
 // parent[] holds the parent id with bit 31 set when the node is the right ('1') child.
-KHG_DEV int khg_tree_build(const int32_t* tab_cnt, int k, uint64_t* heap, uint32_t* nfreq, uint32_t* parent,
-                           int32_t* left, int32_t* right)
+KHG_DEV int khg_tree_build(int k, uint64_t* heap, uint32_t* nfreq, uint32_t* parent, int32_t* left, int32_t* right)
 {
     int n = 0;
+#ifdef KHG_TIMING
+    long long t0 = wall_clock64();
+#endif
     for (int i = 0; i < k; ++i) {  // Huffman.h:91-94
-        uint32_t f = (uint32_t)tab_cnt[i];
-        nfreq[i] = f;
-        left[i] = -1;
-        right[i] = -1;
         heap[n++] = 0;
-        khg_heap_sift_up(heap, n - 1, 0, ((uint64_t)f << 32) | (uint32_t)i);
+        khg_heap_sift_up(heap, n - 1, 0, ((uint64_t)nfreq[i] << 32) | (uint32_t)i);
     }
+#ifdef KHG_TIMING
+    long long t1 = wall_clock64();
+#endif
     int next = k;
     while (n != 1) {  // Huffman.h:96-105
         uint32_t r = (uint32_t)khg_heap_pop(heap, n);
@@ -120,7 +145,22 @@ KHG_DEV int khg_tree_build(const int32_t* tab_cnt, int k, uint64_t* heap, uint32
         khg_heap_sift_up(heap, n - 1, 0, ((uint64_t)sum << 32) | (uint32_t)next);
         next++;
     }
+#ifdef KHG_TIMING
+    long long t2 = wall_clock64();
+    if (k > 100) printf("tree k=%d pushes %lld merges %lld (100MHz ticks)\n", k, t1 - t0, t2 - t1);
+#endif
     return (int)(uint32_t)heap[0];
+}
+
+// All threads: what khg_tree_build expects to find.
+KHG_DEV void khg_tree_prefill(int tid, int nthreads, const int32_t* tab_cnt, int k, uint32_t* nfreq, int32_t* left,
+                              int32_t* right)
+{
+    for (int i = tid; i < k; i += nthreads) {
+        nfreq[i] = (uint32_t)tab_cnt[i];
+        left[i] = -1;
+        right[i] = -1;
+    }
 }
 
 // Huffman.h:57-68 from the leaf upwards: the edge nearest the root is the first (most significant) bit.
@@ -163,12 +203,20 @@ KHG_DEV void khg_table_body(const KhgTableArgs& a, int bid, KhgTableSmem& sh)
     KHG_BARRIER();
     KHG_FOR_THREADS(256)
     {
-        for (int s = tid; s < KHG_NBINS; s += 256)
-            if (hc[s]) {
-                uint32_t i = khg_atomic_add(&sh.k, 1u);
-                efirst[i] = hf[s];
-                ebin[i] = (uint32_t)s;
-            }
+        // 64 consecutive bins per thread, read 16 at a time so the loads overlap
+        for (int g = 0; g < 4; ++g) {
+            const int s0 = tid * 64 + g * 16;
+            uint32_t c[16];
+            KHG_UNROLL
+            for (int j = 0; j < 16; ++j) c[j] = hc[s0 + j];
+            KHG_UNROLL
+            for (int j = 0; j < 16; ++j)
+                if (c[j]) {
+                    uint32_t i = khg_atomic_add(&sh.k, 1u);
+                    efirst[i] = hf[s0 + j];
+                    ebin[i] = (uint32_t)(s0 + j);
+                }
+        }
     }
     KHG_BARRIER();
     const int k = (int)sh.k;
@@ -193,6 +241,8 @@ KHG_DEV void khg_table_body(const KhgTableArgs& a, int bid, KhgTableSmem& sh)
         uint64_t* heap = (uint64_t*)sh.w + 1;               // [4096] u64, element 0 at byte 8 (see khg_heap_pop)
         uint32_t* nfreq = sh.w + 2 * KHG_TREE_LDS_K + 4;    // [8192]
         uint32_t* parent = sh.w + 4 * KHG_TREE_LDS_K + 4;   // [8192]
+        KHG_FOR_THREADS(256) { khg_tree_prefill(tid, 256, tcnt, k, nfreq, left, right); }
+        KHG_BARRIER();
         KHG_FOR_THREADS(256)
         {
             if (tid == 0) {
@@ -200,7 +250,7 @@ KHG_DEV void khg_table_body(const KhgTableArgs& a, int bid, KhgTableSmem& sh)
                     khg_set_status(a.status, -3);
                     sh.root = 0;
                 } else {
-                    sh.root = khg_tree_build(tcnt, k, heap, nfreq, parent, left, right);
+                    sh.root = khg_tree_build(k, heap, nfreq, parent, left, right);
                 }
                 a.tree_root[bid] = sh.root;
             }
@@ -216,10 +266,12 @@ KHG_DEV void khg_table_body(const KhgTableArgs& a, int bid, KhgTableSmem& sh)
         uint64_t* heap = (uint64_t*)g + 1;                  // [16384] u64, element 0 at byte 8
         uint32_t* nfreq = g + 2 * KHG_NBINS + 4;            // [32768]
         uint32_t* parent = g + 4 * KHG_NBINS + 4;           // [32768]
+        KHG_FOR_THREADS(256) { khg_tree_prefill(tid, 256, tcnt, k, nfreq, left, right); }
+        KHG_BARRIER();
         KHG_FOR_THREADS(256)
         {
             if (tid == 0) {
-                sh.root = khg_tree_build(tcnt, k, heap, nfreq, parent, left, right);
+                sh.root = khg_tree_build(k, heap, nfreq, parent, left, right);
                 a.tree_root[bid] = sh.root;
             }
         }

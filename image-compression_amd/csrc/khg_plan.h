@@ -90,21 +90,40 @@ static inline void khg_workspace_sizes(int rows, int cols, KhgWorkspaceSizes* s)
 struct KhgFwdGrid {
     int nstrip, nseg, seg_rows;
 };
-static inline KhgFwdGrid khg_fwd_grid(int ph, int pw)
+// Splits ph rows into equal even-height segments for nstrip column strips.  Workgroups run in rounds of
+// `slots` (resident workgroups on the chip) and each costs its rows plus `halo` warm-up rows, so the
+// segment count is the one that minimises rounds x (rows + halo), with 32 <= rows <= max_rows.
+static inline KhgFwdGrid khg_strip_grid(int ph, int nstrip, int slots, int halo, int max_rows)
 {
     KhgFwdGrid g;
-    g.nstrip = (pw + KHG_STRIP - 1) / KHG_STRIP;
-    int nseg = 1024 / g.nstrip;            // aim for ~1024 workgroups on large planes
-    int maxseg = ph / 32 > 0 ? ph / 32 : 1; // but keep >= 32 rows per segment (8 warm-up rows each)
-    if (nseg > maxseg) nseg = maxseg;
-    int minseg = (ph + KHG_MAX_SEG_ROWS - 1) / KHG_MAX_SEG_ROWS;  // the kernels size LDS tables by this cap
-    if (nseg < minseg) nseg = minseg;
-    if (nseg < 1) nseg = 1;
-    int seg = (ph + nseg - 1) / nseg;
-    seg = (seg + 1) & ~1;
-    g.seg_rows = seg;
-    g.nseg = (ph + seg - 1) / seg;
+    g.nstrip = nstrip;
+    int lo = (ph + max_rows - 1) / max_rows, hi = ph / 32;
+    if (lo < 1) lo = 1;
+    if (hi < lo) hi = lo;
+    long best = -1;
+    for (int n = lo; n <= hi; ++n) {
+        int seg = ((ph + n - 1) / n + 1) & ~1;
+        if (seg > max_rows) continue;
+        int nseg = (ph + seg - 1) / seg;
+        long rounds = ((long)nstrip * nseg + slots - 1) / slots;
+        long cost = rounds * (seg + halo);
+        if (best < 0 || cost < best) {
+            best = cost;
+            g.seg_rows = seg;
+            g.nseg = nseg;
+        }
+    }
+    if (best < 0) {  // ph below one minimal segment
+        g.seg_rows = (ph + 1) & ~1;
+        g.nseg = 1;
+    }
     return g;
+}
+
+// Forward transform: 3 workgroups per CU (LDS), 256 CUs; the reciprocal-divisor table caps the rows.
+static inline KhgFwdGrid khg_fwd_grid(int ph, int pw)
+{
+    return khg_strip_grid(ph, (pw + KHG_STRIP - 1) / KHG_STRIP, 768, 8, KHG_MAX_SEG_ROWS);
 }
 
 // Forward-transform arguments of colour component comp (0 Y, 1 Cb, 2 Cr) at level 1 or 2.
