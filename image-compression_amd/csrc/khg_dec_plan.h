@@ -60,9 +60,11 @@ static inline KhgInvArgs khg_inv_args(const KhgWorkspace& ws, const KhgDecWorksp
         a.dst_pitch = pcol / 2;
     } else {
         a.ph = prow; a.pw = pcol;
-        a.dst = dws.plane[comp];
+        a.dst = dws.plane[comp];  // null for luma: its level-1 pass writes RGB instead
         a.dst_pitch = pcol;
     }
+    a.cb = dws.plane[1];
+    a.cr = dws.plane[2];
     a.hdr = dws.hdr;
     for (int lvl = 0; lvl < 3; ++lvl) khg_make_quant(rows, cols, lvl, comp != 0, &a.q[lvl]);
     *grid = khg_inv_grid(a.ph, a.pw);

@@ -72,7 +72,7 @@ struct KhgBlkInfo {
 };
 
 struct KhgDecWorkspace {
-    double* plane[3];   // reconstructed Y / Cb / Cr (f64)
+    double* plane[3];   // reconstructed Cb / Cr (f64) in [1], [2]; [0] is a stub (luma goes straight to RGB)
     uint32_t* lut;      // [3][KHG_LUT_SIZE] first-level decode tables
     uint32_t* lut2;     // [3][KHG_LUT_SIZE][KHG_LUT2_SIZE] second-level tables (only rows of missing prefixes are filled)
     KhgBlkInfo* blk;    // per workgroup, planes concatenated
@@ -117,7 +117,7 @@ struct KhgDecArgs {
 static inline void khg_dec_workspace_sizes(int rows, int cols, KhgDecWorkspaceSizes* s)
 {
     size_t ny = (size_t)rows * cols, nc = ny / 4;
-    s->plane[0] = ny * sizeof(double);
+    s->plane[0] = 64;  // the luma plane is converted to RGB as it is produced and never stored
     s->plane[1] = s->plane[2] = nc * sizeof(double);
     size_t blocks = (size_t)khg_max_blocks(ny) + 2 * (size_t)khg_max_blocks(nc);
     s->lut = 3 * (size_t)KHG_LUT_SIZE * sizeof(uint32_t);

@@ -1,11 +1,6 @@
 // khg_host_decode.inl -- host side of the decode path and the quality metrics
 // (included by khugle_hip.hip).
 
-__global__ __launch_bounds__(256) void khg_rgb_kernel(KhgRgbArgs a)
-{
-    khg_rgb_body(a, blockIdx.x, gridDim.x);
-}
-
 extern "C" int khg_peek(const uint8_t* comp, size_t len, khg_header* hdr)
 {
     if (!comp || !hdr) return KHG_ERR_ARG;
@@ -38,8 +33,8 @@ extern "C" int khg_decode_dev(khg_ctx* c, const uint8_t* d_comp, size_t len, int
 {
     int rc = khg_check_image(c, rows, cols);
     if (rc) return rc;
-    if (!d_comp || !d_r || !d_g || !d_b || ((uintptr_t)d_comp & 3) || ((uintptr_t)d_r & 3) || ((uintptr_t)d_g & 3) ||
-        ((uintptr_t)d_b & 3))
+    if (!d_comp || !d_r || !d_g || !d_b || ((uintptr_t)d_comp & 3) || ((uintptr_t)d_r & 7) || ((uintptr_t)d_g & 7) ||
+        ((uintptr_t)d_b & 7))
         return KHG_ERR_ARG;
     if (len < 36 + 24) return KHG_ERR_FORMAT;
     hipStream_t st = (hipStream_t)stream;
@@ -54,18 +49,17 @@ extern "C" int khg_decode_dev(khg_ctx* c, const uint8_t* d_comp, size_t len, int
     KhgFwdGrid gr;
     for (int p = 0; p < 3; ++p) {  // Decompress.h:274-276
         KhgInvArgs a = khg_inv_args(c->ws, c->dws, rows, cols, p, 2, &gr);
-        hipLaunchKernelGGL((khg_inv_kernel<2>), dim3(gr.nstrip * gr.nseg), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((khg_inv_kernel<2, false>), dim3(gr.nstrip * gr.nseg), dim3(256), 0, st, a);
     }
-    for (int p = 0; p < 3; ++p) {  // Decompress.h:278-280
+    for (int p = 2; p >= 0; --p) {  // Decompress.h:278-280; luma last: it also does Decompress.h:282 + Main.cpp:307-315
         KhgInvArgs a = khg_inv_args(c->ws, c->dws, rows, cols, p, 1, &gr);
-        hipLaunchKernelGGL((khg_inv_kernel<1>), dim3(gr.nstrip * gr.nseg), dim3(256), 0, st, a);
+        if (p == 0) {
+            a.r = d_r; a.g = d_g; a.b = d_b;
+            hipLaunchKernelGGL((khg_inv_kernel<1, true>), dim3(gr.nstrip * gr.nseg), dim3(256), 0, st, a);
+        } else {
+            hipLaunchKernelGGL((khg_inv_kernel<1, false>), dim3(gr.nstrip * gr.nseg), dim3(256), 0, st, a);
+        }
     }
-    KhgRgbArgs ra;
-    ra.y = c->dws.plane[0]; ra.cb = c->dws.plane[1]; ra.cr = c->dws.plane[2];
-    ra.r = d_r; ra.g = d_g; ra.b = d_b;
-    ra.rows = rows; ra.cols = cols;
-    unsigned grid = (unsigned)(rows < 4096 ? rows : 4096);
-    hipLaunchKernelGGL(khg_rgb_kernel, dim3(grid), dim3(256), 0, st, ra);
     KHG_HIP(hipGetLastError());
     KHG_HIP(hipMemcpyAsync(c->h_res, c->ws.res, sizeof(KhgResult), hipMemcpyDeviceToHost, st));
     KHG_HIP(hipEventRecord(c->done, st));

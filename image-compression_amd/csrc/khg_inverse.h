@@ -9,7 +9,9 @@
 //            feeds the streaming inverse lifting pipeline in registers, and stores the two
 //            finished natural-order rows in LDS tile T
 //   rows   : each thread inverse-lifts a run of 16 outputs of one row from 12 low + 12 high
-//            values of T and writes them to the destination plane.
+//            values of T and writes them to the destination plane -- or, for the luma plane at level 1,
+//            converts them with the finished chroma planes to RGB (Colorspace.h:25-36) and writes the
+//            u8 image directly, so the f64 luma plane never exists in memory.
 #pragma once
 #include "khg_common.h"
 #include "khg_decode.h"
@@ -34,6 +36,9 @@ struct KhgInvArgs {
     int seg_rows;         // output rows per workgroup segment (even)
     int nstrip;
     KhgQuant q[3];        // quantiser constants of this plane type for presets 0..2
+    // RGB variant (level 1 of the luma plane): the finished chroma planes and the output image
+    const double *cb, *cr;  // (ph/2) x (pw/2)
+    uint8_t *r, *g, *b;     // ph x pw, pitch pw
 };
 
 struct KhgInvSmem {
@@ -84,7 +89,27 @@ KHG_DEV double khg_inv_load(const KhgInvArgs& a, const KhgQuant& qc, int lvl, in
     return (double)q * khg_divisor(qc, band, xo, yo, lvl);  // Decompress.h:105, 120-121
 }
 
-template <int LEVEL>
+KHG_DEV uint8_t khg_clamp_u8(double v)
+{
+    // max(0, min(v, 255)) with the Win32 macros (a<b?a:b), (a>b?a:b), then truncation to unsigned char
+    double m = (v < 255.0) ? v : 255.0;
+    double c = (0.0 > m) ? 0.0 : m;
+    return (uint8_t)c;
+}
+
+// Colorspace.h:25-36 + Main.cpp:307-315 for the two pixels that share one chroma site: products and sums
+// left to right, clamp, truncate.  Returns the pixels' bytes in bits 0..7 and 8..15 of rgb[0..2].
+KHG_DEV void khg_rgb_pair(double y0, double y1, double Cb, double Cr, uint32_t rgb[3])
+{
+    const double rr = Cr * 1.402, gb = Cb * -0.34414, gr = Cr * -0.71414, bb = Cb * 1.772;
+    rgb[0] = (uint32_t)khg_clamp_u8(y0 * 1 + rr) | ((uint32_t)khg_clamp_u8(y1 * 1 + rr) << 8);
+    rgb[1] = (uint32_t)khg_clamp_u8(y0 * 1 + gb + gr) | ((uint32_t)khg_clamp_u8(y1 * 1 + gb + gr) << 8);
+    rgb[2] = (uint32_t)khg_clamp_u8(y0 * 1 + bb) | ((uint32_t)khg_clamp_u8(y1 * 1 + bb) << 8);
+}
+
+// RGB = true (level 1 of the luma plane only): the row phase does not store the luma samples but combines
+// them with the already reconstructed chroma planes and writes the u8 image.
+template <int LEVEL, bool RGB = false>
 KHG_DEV void khg_inv_strip_body(const KhgInvArgs& a, int bid, KhgInvSmem& sh)
 {
     const int strip = bid % a.nstrip, seg = bid / a.nstrip;
@@ -144,15 +169,48 @@ KHG_DEV void khg_inv_strip_body(const KhgInvArgs& a, int bid, KhgInvSmem& sh)
             if (run < KHG_ISTRIP / 16 && pair >= k0 && pair < k1 && gx0 < a.pw) {
                 const double* lo = &sh.T[rr * KHG_T_PITCH + run * 8];
                 const double* hi = lo + KHG_IHALF;
-                double* out = a.dst + (size_t)gy * a.dst_pitch + gx0;
+                double* out = RGB ? nullptr : a.dst + (size_t)gy * a.dst_pitch + gx0;
+                const int nv = a.pw - gx0 >= 16 ? 16 : a.pw - gx0;  // 8 or 16 outputs are inside (pw = 0 mod 8)
+                double cbv[8], crv[8], yv[16];
+                if (RGB) {  // issued first: in flight during the lifting below
+                    const size_t cpos = (size_t)(gy >> 1) * (a.pw >> 1) + (gx0 >> 1);
+                    KHG_UNROLL
+                    for (int c = 0; c < 8; ++c) {
+                        cbv[c] = 2 * c < nv ? a.cb[cpos + c] : 0.0;
+                        crv[c] = 2 * c < nv ? a.cr[cpos + c] : 0.0;
+                    }
+                }
                 KhgILift st = {0, 0, 0, 0};
                 KHG_UNROLL
                 for (int i = 0; i < 12; ++i) {
                     double xe, xod;
                     khg_inv_step(st, lo[i], hi[i], xe, xod);
-                    if (i >= 4 && gx0 + 2 * (i - 4) < a.pw) {  // pw is even: a pair never straddles the edge
+                    if (RGB) {
+                        if (i >= 4) {
+                            yv[2 * (i - 4)] = xe;
+                            yv[2 * (i - 4) + 1] = xod;
+                        }
+                    } else if (i >= 4 && 2 * (i - 4) < nv) {  // pw is even: a pair never straddles the edge
                         out[2 * (i - 4)] = xe;
                         out[2 * (i - 4) + 1] = xod;
+                    }
+                }
+                if (RGB) {
+                    uint64_t pk[3][2] = {{0, 0}, {0, 0}, {0, 0}};  // 8 pixels per 64-bit word, first pixel lowest
+                    KHG_UNROLL
+                    for (int c = 0; c < 8; ++c) {
+                        uint32_t rgb[3];
+                        khg_rgb_pair(yv[2 * c], yv[2 * c + 1], cbv[c], crv[c], rgb);
+                        for (int ch = 0; ch < 3; ++ch) pk[ch][c >> 2] |= (uint64_t)rgb[ch] << (16 * (c & 3));
+                    }
+                    const size_t p = (size_t)gy * a.pw + gx0;
+                    *(uint64_t*)(a.r + p) = pk[0][0];
+                    *(uint64_t*)(a.g + p) = pk[1][0];
+                    *(uint64_t*)(a.b + p) = pk[2][0];
+                    if (nv == 16) {
+                        *(uint64_t*)(a.r + p + 8) = pk[0][1];
+                        *(uint64_t*)(a.g + p + 8) = pk[1][1];
+                        *(uint64_t*)(a.b + p + 8) = pk[2][1];
                     }
                 }
             }
@@ -161,49 +219,3 @@ KHG_DEV void khg_inv_strip_body(const KhgInvArgs& a, int bid, KhgInvSmem& sh)
     }
 }
 
-// Colorspace.h:25-36 + Main.cpp:307-315: 4 pixels per thread.
-struct KhgRgbArgs {
-    const double *y, *cb, *cr;
-    uint8_t *r, *g, *b;
-    int rows, cols;
-};
-
-KHG_DEV uint8_t khg_clamp_u8(double v)
-{
-    // max(0, min(v, 255)) with the Win32 macros (a<b?a:b), (a>b?a:b), then truncation to unsigned char
-    double m = (v < 255.0) ? v : 255.0;
-    double c = (0.0 > m) ? 0.0 : m;
-    return (uint8_t)c;
-}
-
-KHG_DEV void khg_rgb_body(const KhgRgbArgs& a, uint32_t bid, uint32_t nblk)
-{
-    const int cw = a.cols / 2;
-    const uint32_t qrow = (uint32_t)a.cols / 4;               // quads per row
-    const uint32_t per = (qrow + 255) / 256;                  // quads of one row handled per thread
-    KHG_FOR_THREADS(256)
-    {
-      for (uint32_t yy = bid; yy < (uint32_t)a.rows; yy += nblk)    // one row per workgroup step
-        for (uint32_t k = 0; k < per; ++k) {
-            uint32_t qx = k * 256 + (uint32_t)tid;
-            if (qx >= qrow) break;
-            uint32_t xx = qx * 4;
-            size_t p = (size_t)yy * a.cols + xx;
-            uint32_t pr = 0, pg = 0, pb = 0;
-            for (int i = 0; i < 4; ++i) {
-                double Y = a.y[p + i];
-                size_t c = (size_t)(yy / 2) * cw + (xx + i) / 2;
-                double Cb = a.cb[c], Cr = a.cr[c];
-                double R = Y * 1 + Cr * 1.402;
-                double G = Y * 1 + Cb * -0.34414 + Cr * -0.71414;
-                double B = Y * 1 + Cb * 1.772;
-                pr |= (uint32_t)khg_clamp_u8(R) << (8 * i);
-                pg |= (uint32_t)khg_clamp_u8(G) << (8 * i);
-                pb |= (uint32_t)khg_clamp_u8(B) << (8 * i);
-            }
-            *(uint32_t*)(a.r + p) = pr;
-            *(uint32_t*)(a.g + p) = pg;
-            *(uint32_t*)(a.b + p) = pb;
-        }
-    }
-}

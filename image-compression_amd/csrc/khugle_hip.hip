@@ -85,11 +85,11 @@ __global__ __launch_bounds__(256) void khg_dec_write_kernel(KhgDecArgs a)
     khg_dec_write_body(a, blockIdx.x, sh);
 }
 
-template <int LEVEL>
+template <int LEVEL, bool RGB>
 __global__ __launch_bounds__(256) void khg_inv_kernel(KhgInvArgs a)
 {
     __shared__ KhgInvSmem sh;
-    khg_inv_strip_body<LEVEL>(a, (int)blockIdx.x, sh);
+    khg_inv_strip_body<LEVEL, RGB>(a, (int)blockIdx.x, sh);
 }
 
 __global__ __launch_bounds__(256) void khg_ssim_kernel(KhgSsimArgs a)

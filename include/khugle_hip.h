@@ -76,7 +76,8 @@ int khg_encode_result(khg_ctx *ctx, size_t *out_len);
  * YCbCr2RGB (Colorspace.h:25-36) and the double -> u8 truncation of Main.cpp:307-315. */
 int khg_peek(const uint8_t *comp, size_t len, khg_header *hdr);  /* host bytes; validates the header */
 int khg_decode(khg_ctx *ctx, const uint8_t *comp, size_t len, uint8_t *r, uint8_t *g, uint8_t *b);
-/* rows/cols are what the caller expects the file to hold (checked against the header on the device). */
+/* rows/cols are what the caller expects the file to hold (checked against the header on the device).
+ * d_comp must be 4-byte aligned, d_r / d_g / d_b 8-byte aligned (KHG_ERR_ARG otherwise). */
 int khg_decode_dev(khg_ctx *ctx, const uint8_t *d_comp, size_t len, int rows, int cols,
                    uint8_t *d_r, uint8_t *d_g, uint8_t *d_b, void *stream);
 /* Waits for the context's last enqueued work and returns its device-side status. */

@@ -135,15 +135,15 @@ int khgsim_decode(const uint8_t* comp, size_t len, int rows, int cols, uint8_t* 
         KhgInvArgs a = khg_inv_args(S.ws, S.dws, rows, cols, p, 2, &gr);
         for (int bid = 0; bid < gr.nstrip * gr.nseg; ++bid) khg_inv_strip_body<2>(a, bid, *ish);
     }
-    for (int p = 0; p < 3; ++p) {
+    for (int p = 2; p >= 0; --p) {
         KhgInvArgs a = khg_inv_args(S.ws, S.dws, rows, cols, p, 1, &gr);
-        for (int bid = 0; bid < gr.nstrip * gr.nseg; ++bid) khg_inv_strip_body<1>(a, bid, *ish);
+        a.r = r; a.g = g; a.b = b;
+        for (int bid = 0; bid < gr.nstrip * gr.nseg; ++bid) {
+            if (p == 0) khg_inv_strip_body<1, true>(a, bid, *ish);
+            else khg_inv_strip_body<1, false>(a, bid, *ish);
+        }
     }
     delete ish;
-    KhgRgbArgs ra;
-    ra.y = S.dws.plane[0]; ra.cb = S.dws.plane[1]; ra.cr = S.dws.plane[2];
-    ra.r = r; ra.g = g; ra.b = b; ra.rows = rows; ra.cols = cols;
-    for (uint32_t bid = 0; bid < 4; ++bid) khg_rgb_body(ra, bid, 4);
     size_t ny = (size_t)rows * cols;
     if (qy) memcpy(qy, S.ws.sym[0], ny * 2);
     if (qcb) memcpy(qcb, S.ws.sym[1], ny / 4 * 2);
