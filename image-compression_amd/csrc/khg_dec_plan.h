@@ -32,7 +32,7 @@ static inline KhgDecArgs khg_dec_args(const KhgWorkspace& ws, const KhgDecWorksp
     }
     d.nblocks = blk;
     d.blk = dws.blk;
-    d.submap = dws.submap;
+    d.walk = dws.walk;
     return d;
 }
 

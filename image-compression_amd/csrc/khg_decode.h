@@ -76,12 +76,12 @@ struct KhgDecWorkspace {
     uint32_t* lut;      // [3][KHG_LUT_SIZE] first-level decode tables
     uint32_t* lut2;     // [3][KHG_LUT_SIZE][KHG_LUT2_SIZE] second-level tables (only rows of missing prefixes are filled)
     KhgBlkInfo* blk;    // per workgroup, planes concatenated
-    uint16_t* submap;   // [workgroup][KHG_MAXOFF][KHG_DEC_BLOCK] subsequence maps
+    uint32_t* walk;     // [workgroup][KHG_DEC_BLOCK][maxlen]: see khg_dec_map_body
     KhgDecHeader* hdr;
 };
 
 struct KhgDecWorkspaceSizes {
-    size_t plane[3], lut, lut2, blk, submap;
+    size_t plane[3], lut, lut2, blk, walk;
 };
 
 static inline uint32_t khg_max_blocks(uint64_t nsym)
@@ -107,7 +107,7 @@ struct KhgDecArgs {
     uint32_t* lut;         // [3][KHG_LUT_SIZE]
     uint32_t* lut2;        // [3][KHG_LUT_SIZE][KHG_LUT2_SIZE]
     KhgBlkInfo* blk;       // [nblocks]
-    uint16_t* submap;      // [nblocks][KHG_MAXOFF][KHG_DEC_BLOCK]
+    uint32_t* walk;        // [nblocks][KHG_DEC_BLOCK * KHG_MAXOFF] words; a workgroup uses [t * maxlen + o]
     uint32_t blk0[3];      // first workgroup index of each plane (capacity layout)
     uint32_t nblocks;
     int16_t* sym[3];
@@ -123,7 +123,7 @@ static inline void khg_dec_workspace_sizes(int rows, int cols, KhgDecWorkspaceSi
     s->lut = 3 * (size_t)KHG_LUT_SIZE * sizeof(uint32_t);
     s->lut2 = 3 * (size_t)KHG_LUT_SIZE * KHG_LUT2_SIZE * sizeof(uint32_t);
     s->blk = blocks * sizeof(KhgBlkInfo);
-    s->submap = blocks * KHG_MAXOFF * KHG_DEC_BLOCK * sizeof(uint16_t);
+    s->walk = blocks * KHG_MAXOFF * KHG_DEC_BLOCK * sizeof(uint32_t);
 }
 
 KHG_DEV int32_t khg_load_le32(const uint8_t* p)
@@ -489,7 +489,8 @@ struct KhgDecSmem {
 };
 
 // Stage the LUT and the workgroup's span of the stream (byte-swapped words) in LDS.
-KHG_DEV KhgBitsL khg_dec_stage(const KhgDecArgs& a, int p, uint32_t blk_begin, KhgDecSmem& sh)
+template <class SMEM>
+KHG_DEV KhgBitsL khg_dec_stage(const KhgDecArgs& a, int p, uint32_t blk_begin, SMEM& sh)
 {
     const uint32_t* words = (const uint32_t*)a.comp;
     const uint32_t nwords = (uint32_t)(a.len >> 2);
@@ -649,18 +650,24 @@ KHG_DEV void khg_dec_map_body(const KhgDecArgs& a, uint32_t blk, KhgDecSmem& sh)
     KHG_BARRIER();
     KHG_FOR_THREADS(256)
     {
-        // compose the 256 subsequence maps: one lane per start offset of the workgroup
+        // compose the 256 subsequence maps: one lane per start offset of the workgroup.  Along the way the
+        // lane notes, for every subsequence, the offset it is entered at and the codewords before it:
+        // walk[t * M + o] = (entry offset << 24) | count, for a workgroup entered at offset o.  Once the
+        // chain has fixed the workgroup's true entry offset, column o of this table is all the write
+        // kernel needs to start 256 independent decoders.
         if ((uint32_t)tid < M) {
+            uint32_t* gw = a.walk + (size_t)blk * KHG_MAXOFF * KHG_DEC_BLOCK;
             uint32_t off = (uint32_t)tid, tot = 0;
-            for (uint32_t t = 0; t < KHG_DEC_BLOCK && off != KHG_OFF_NONE; ++t) {
-                uint16_t e = sh.map[off * KHG_DEC_BLOCK + t];
-                tot += khg_map_cnt(e);
-                off = khg_map_arr(e);
+            for (uint32_t t = 0; t < KHG_DEC_BLOCK; ++t) {
+                gw[t * M + (uint32_t)tid] = (off << 24) | tot;
+                if (off != KHG_OFF_NONE) {
+                    uint16_t e = sh.map[off * KHG_DEC_BLOCK + t];
+                    tot += khg_map_cnt(e);
+                    off = khg_map_arr(e);
+                }
             }
             a.blk[blk].map[tid] = (off << 24) | tot;
         }
-        uint16_t* gm = a.submap + (size_t)blk * KHG_MAXOFF * KHG_DEC_BLOCK;
-        for (uint32_t o = 0; o < M; ++o) gm[o * KHG_DEC_BLOCK + tid] = sh.map[o * KHG_DEC_BLOCK + tid];
     }
 }
 
@@ -732,8 +739,15 @@ KHG_DEV void khg_dec_chain_body(const KhgDecArgs& a, int bid, KhgDecChainSmem& s
     }
 }
 
-// One workgroup = 256 subsequences: resolve every exact start, then decode and store the symbols.
-KHG_DEV void khg_dec_write_body(const KhgDecArgs& a, uint32_t blk, KhgDecSmem& sh)
+struct KhgDecWriteSmem {
+    uint32_t lut[KHG_LUT_SIZE];
+    uint32_t stage[KHG_STAGE_LDS];
+    uint32_t pre[KHG_DEC_BLOCK + 1];
+};
+
+// One workgroup = 256 subsequences: every thread looks up its exact start and output position, then
+// decodes and stores its symbols.
+KHG_DEV void khg_dec_write_body(const KhgDecArgs& a, uint32_t blk, KhgDecWriteSmem& sh)
 {
     if (!a.hdr->ok || a.res->status != 0) return;
     const int p = khg_block_plane(a, blk);
@@ -743,104 +757,67 @@ KHG_DEV void khg_dec_write_body(const KhgDecArgs& a, uint32_t blk, KhgDecSmem& s
     if (blk_begin >= nbits) return;
     const uint32_t M = (uint32_t)a.hdr->maxlen[p];
     if (M == 0 || M > KHG_MAXOFF) return;
+    const uint32_t entry = a.blk[blk].start_off;
+    if (entry == KHG_OFF_NONE) return;  // the stream broke off before this workgroup
     const int32_t* left = a.tree_left + (size_t)p * 2 * KHG_NBINS;
     const int32_t* right = a.tree_right + (size_t)p * 2 * KHG_NBINS;
     const int32_t* tsym = a.tab_sym + (size_t)p * KHG_NBINS;
     const uint32_t* lut2 = a.lut2 + (size_t)p * KHG_LUT_SIZE * KHG_LUT2_SIZE;
     const int onebit = a.hdr->one_bit[p], onesym = a.hdr->one_sym[p];
-    uint32_t* s_off = sh.mask;                       // the codeword-start maps are not needed here:
-    uint32_t* s_cnt = sh.mask + KHG_DEC_BLOCK;       // their space holds start offset, count and
-    uint32_t* s_pre = sh.mask + 2 * KHG_DEC_BLOCK;   // count prefix of every subsequence
+    const uint32_t* gw = a.walk + (size_t)blk * KHG_MAXOFF * KHG_DEC_BLOCK;
+#ifdef KHG_TIMING
+    const long long tm0 = wall_clock64();
+#endif
     const KhgBitsL bits = khg_dec_stage(a, p, blk_begin, sh);
+    uint32_t offs[KHG_NSLOT(256)];
     KHG_FOR_THREADS(256)
     {
-        const uint16_t* gm = a.submap + (size_t)blk * KHG_MAXOFF * KHG_DEC_BLOCK;
-        for (uint32_t o = 0; o < M; ++o) sh.map[o * KHG_DEC_BLOCK + tid] = gm[o * KHG_DEC_BLOCK + tid];
+        const uint32_t w = gw[(uint32_t)tid * M + entry];
+        offs[KHG_SLOT] = w >> 24;
+        sh.pre[tid] = w & 0xFFFFFFu;
+        if (tid == 0) sh.pre[KHG_DEC_BLOCK] = a.blk[blk].map[entry] & 0xFFFFFFu;  // codewords of the whole workgroup
     }
     KHG_BARRIER();
     KHG_FOR_THREADS(256)
     {
-        if (tid == 0) {
-            uint32_t off = a.blk[blk].start_off;
-            for (uint32_t t = 0; t < KHG_DEC_BLOCK; ++t) {
-                s_off[t] = off;
-                uint32_t c = 0;
-                if (off != KHG_OFF_NONE) {
-                    uint16_t e = sh.map[off * KHG_DEC_BLOCK + t];
-                    c = khg_map_cnt(e);
-                    off = khg_map_arr(e);
-                }
-                s_cnt[t] = c;
-            }
-        }
-    }
-    KHG_BARRIER();
-    KHG_FOR_THREADS(256)
-    {
-        if (tid < 16) {  // exclusive scan of the counts inside each group of 16 threads
-            uint32_t run = 0;
-            for (int i = 0; i < 16; ++i) {
-                s_pre[tid * 16 + i] = run;
-                run += s_cnt[tid * 16 + i];
-            }
-            sh.grp[tid] = run;
-        }
-    }
-    KHG_BARRIER();
-    KHG_FOR_THREADS(256)
-    {
-        const uint32_t off = s_off[tid], cnt = s_cnt[tid];
+        const uint32_t off = offs[KHG_SLOT], cnt = sh.pre[tid + 1] - sh.pre[tid];
         if (off != KHG_OFF_NONE && cnt) {
-            uint32_t o = a.blk[blk].out + s_pre[tid];
-            for (int g = 0; g < (tid >> 4); ++g) o += sh.grp[g];
-            uint32_t pos = blk_begin + (uint32_t)tid * KHG_SUB_BITS + off;
-            int16_t* q = a.sym[p];
+            const uint32_t o = a.blk[blk].out + sh.pre[tid];
+            const uint32_t pos = blk_begin + (uint32_t)tid * KHG_SUB_BITS + off;
             const uint32_t lim = a.n[p];
+            const uint32_t todo = o >= lim ? 0 : (cnt < lim - o ? cnt : lim - o);  // never store past the plane
+            int16_t* q = a.sym[p] + o;
             KhgCursor cur;
             khg_cur_init(cur, bits, pos);
-            // symbols are gathered four at a time and stored as one 8-byte word where this thread owns
-            // the whole aligned group (q is 8-byte aligned at multiples of four symbols)
-            uint64_t pack = 0;
+            const uint64_t z4 = 0x0001000100010001ull * (uint64_t)(uint16_t)(int16_t)onesym;
+            // Each trip takes a run of the 1-bit code (possibly empty) and then one other codeword, so the
+            // lanes of a wave stay in step through "zeros, then a value".  A run goes out as up to eight
+            // 8-byte stores plus a 4- and a 2-byte one, all straight-line; the stores are only 2-byte
+            // aligned, which global memory accepts.
             uint32_t i = 0;
-            auto put = [&](int s) {
-                const uint32_t idx = o + i;
-                pack |= (uint64_t)(uint16_t)(int16_t)s << (16 * (idx & 3u));
-                if ((idx & 3u) == 3u || i + 1 == cnt) {
-                    const uint32_t g0 = idx & ~3u, first = g0 > o ? g0 : o;
-                    if (first == g0 && (idx & 3u) == 3u && idx < lim) {
-                        *(uint64_t*)(q + g0) = pack;
-                    } else {
-                        for (uint32_t k2 = first; k2 <= idx; ++k2)
-                            if (k2 < lim) q[k2] = (int16_t)(pack >> (16 * (k2 & 3u)));
-                    }
-                    pack = 0;
-                }
-                ++i;
-            };
-            while (i < cnt) {
-                uint32_t r = khg_cur_runlen(cur, onebit, cnt - i);
-                if (r) {  // r copies of the 1-bit code's symbol: whole aligned groups go out as constants
+            while (i < todo) {
+                const uint32_t r = khg_cur_runlen(cur, onebit, todo - i);  // 0..32
+                if (r) {
                     khg_cur_skip(cur, bits, r);
-                    while (r && ((o + i) & 3u)) {
-                        put(onesym);
-                        --r;
-                    }
-                    const uint64_t z4 = 0x0001000100010001ull * (uint64_t)(uint16_t)(int16_t)onesym;
-                    while (r >= 4 && o + i + 4 <= lim) {
-                        *(uint64_t*)(q + o + i) = z4;
-                        i += 4;
-                        r -= 4;
-                    }
-                    while (r) {
-                        put(onesym);
-                        --r;
-                    }
-                    continue;
+                    int16_t* d = q + i;
+                    KHG_UNROLL
+                    for (uint32_t k4 = 0; k4 < 8; ++k4)
+                        if (4 * k4 + 4 <= r) __builtin_memcpy(d + 4 * k4, &z4, 8);
+                    if (r & 2) __builtin_memcpy(d + (r & ~3u), &z4, 4);
+                    if (r & 1) d[r - 1] = (int16_t)onesym;
+                    i += r;
                 }
-                int s;
-                if (khg_cur_decode(cur, bits, sh.lut, lut2, left, right, tsym, &s) == 0) break;
-                put(s);
+                if (i < todo && r < 32) {  // a run cut at 32 may simply go on
+                    int s;
+                    if (khg_cur_decode(cur, bits, sh.lut, lut2, left, right, tsym, &s) == 0) break;
+                    q[i] = (int16_t)s;
+                    ++i;
+                }
             }
         }
+#ifdef KHG_TIMING
+        if ((tid & 63) == 0 && (blk % 37) == 0)
+            printf("write blk %u wave %d start %lld dur %lld (10ns)\n", blk, tid >> 6, tm0, wall_clock64() - tm0);
+#endif
     }
 }

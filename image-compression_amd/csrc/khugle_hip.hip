@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void khg_dec_chain_kernel(KhgDecArgs a)
 
 __global__ __launch_bounds__(256) void khg_dec_write_kernel(KhgDecArgs a)
 {
-    __shared__ KhgDecSmem sh;
+    __shared__ KhgDecWriteSmem sh;
     khg_dec_write_body(a, blockIdx.x, sh);
 }
 
@@ -186,7 +186,7 @@ extern "C" int khg_ctx_create(int device, int max_rows, int max_cols, khg_ctx** 
     size_t o_cb = take(s.chunk_bits), o_co = take(s.chunk_off), o_res = take(sizeof(KhgResult));
     size_t o_plane[3];
     for (int p = 0; p < 3; ++p) o_plane[p] = take(ds.plane[p]);
-    size_t o_lut = take(ds.lut), o_lut2 = take(ds.lut2), o_blk = take(ds.blk), o_submap = take(ds.submap), o_hdr = take(sizeof(KhgDecHeader));
+    size_t o_lut = take(ds.lut), o_lut2 = take(ds.lut2), o_blk = take(ds.blk), o_walk = take(ds.walk), o_hdr = take(sizeof(KhgDecHeader));
     size_t o_ssim = take(nblk * sizeof(double)), o_sse = take(64);
     c->slab_bytes = total;
     if (hipMalloc(&c->slab, total) != hipSuccess) { delete c; return KHG_ERR_NOMEM; }
@@ -202,7 +202,7 @@ extern "C" int khg_ctx_create(int device, int max_rows, int max_cols, khg_ctx** 
     c->dws.lut = (uint32_t*)(base + o_lut);
     c->dws.lut2 = (uint32_t*)(base + o_lut2);
     c->dws.blk = (KhgBlkInfo*)(base + o_blk);
-    c->dws.submap = (uint16_t*)(base + o_submap);
+    c->dws.walk = (uint32_t*)(base + o_walk);
     c->dws.hdr = (KhgDecHeader*)(base + o_hdr);
     c->ssim_blocks = (double*)(base + o_ssim);
     c->sse = (unsigned long long*)(base + o_sse);

@@ -39,7 +39,7 @@ struct SimWs {
         dws.lut = alloc<uint32_t>(d.lut);
         dws.lut2 = alloc<uint32_t>(d.lut2);
         dws.blk = alloc<KhgBlkInfo>(d.blk);
-        dws.submap = alloc<uint16_t>(d.submap);
+        dws.walk = alloc<uint32_t>(d.walk);
         dws.hdr = alloc<KhgDecHeader>(sizeof(KhgDecHeader));
     }
     KhgDecWorkspace dws;
@@ -122,12 +122,14 @@ int khgsim_decode(const uint8_t* comp, size_t len, int rows, int cols, uint8_t* 
     for (int p = 0; p < 3; ++p) khg_dec_tree_body(d, p, *tsh);
     delete tsh;
     KhgDecSmem* lsh = new KhgDecSmem;
+    KhgDecWriteSmem* wsh = new KhgDecWriteSmem;
     KhgDecChainSmem* ssh = new KhgDecChainSmem;
     for (uint32_t b_ = 0; b_ < d.nblocks; ++b_) khg_dec_map_body(d, b_, *lsh);
     for (int p = 0; p < 3; ++p) khg_dec_chain_body(d, p, *ssh);
     if (passes_used) *passes_used = 1;
-    for (uint32_t b_ = 0; b_ < d.nblocks; ++b_) khg_dec_write_body(d, b_, *lsh);
+    for (uint32_t b_ = 0; b_ < d.nblocks; ++b_) khg_dec_write_body(d, b_, *wsh);
     delete lsh;
+    delete wsh;
     delete ssh;
     KhgInvSmem* ish = new KhgInvSmem;
     KhgFwdGrid gr;
