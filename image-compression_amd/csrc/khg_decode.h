@@ -35,6 +35,7 @@ enum {
     KHG_LUT2_BITS = 8,        // second-level tables: the next 8 bits after a first-level miss
     KHG_LUT2_SIZE = 1 << KHG_LUT2_BITS,
     KHG_MAXOFF = KHG_MAX_CODE_BITS,  // start offsets 0..55
+    KHG_RUN_ILP = 4,          // rejoining runs a thread advances side by side (khg_dec_map_body)
     KHG_OFF_TEMP = 62,        // map entry not final yet: the count field holds the landing offset
     KHG_OFF_NONE = 63         // no codeword starts from here on (the stream has ended)
 };
@@ -528,6 +529,9 @@ KHG_DEV void khg_dec_map_body(const KhgDecArgs& a, uint32_t blk, KhgDecSmem& sh)
     const int32_t* tsym = a.tab_sym + (size_t)p * KHG_NBINS;
     const uint32_t* lut2 = a.lut2 + (size_t)p * KHG_LUT_SIZE * KHG_LUT2_SIZE;
     const int onebit = a.hdr->one_bit[p];
+#ifdef KHG_TIMING
+    const long long tmap0 = wall_clock64();
+#endif
     const KhgBitsL bits = khg_dec_stage(a, p, blk_begin, sh);
     KHG_BARRIER();
 
@@ -548,42 +552,34 @@ KHG_DEV void khg_dec_map_body(const KhgDecArgs& a, uint32_t blk, KhgDecSmem& sh)
             }
             map[o * KHG_DEC_BLOCK] = e;
         }
-        // 2. offsets whose first codeword leaves the first M bits run on; the first run records
-        //    its codeword starts, later runs stop when they land on one of them
+        // 2. offsets whose first codeword leaves the first M bits run on.  The first such run (from the
+        //    highest offset) goes through the whole subsequence and records its codeword starts.
+        int oo = (int)M;
         bool have_main = false;
         uint32_t main_arr = KHG_OFF_NONE;
-        // (every lane picks ITS next such offset per trip, so a wave runs its lanes' j-th runs
-        //  together: the long first runs side by side, then the short rejoining ones)
-        for (uint32_t oo = M;;) {
-            uint16_t e0 = 0;
-            bool found = false;
-            while (oo-- > 0) {
-                e0 = map[oo * KHG_DEC_BLOCK];
-                if (khg_map_arr(e0) == KHG_OFF_TEMP && khg_map_cnt(e0) >= M) {
-                    found = true;
-                    break;
-                }
-            }
-            if (!found) break;
+        while (oo > 0) {
+            --oo;
+            const uint16_t e0 = map[oo * KHG_DEC_BLOCK];
+            if (khg_map_arr(e0) != KHG_OFF_TEMP || khg_map_cnt(e0) < M) continue;
             uint32_t pos = sub_begin + khg_map_cnt(e0), n = 1;
-            bool joined = false, dead = false;
-            const bool is_main = !have_main;
+            bool dead = false;
             KhgCursor cur;
             if (pos < end) khg_cur_init(cur, bits, pos);
-            if (is_main) {
-                for (uint32_t w = 0; w < KHG_SUB_WORDS; ++w) mask[w * KHG_DEC_BLOCK] = 0;
-                while (pos < end) {
-                    const uint32_t rel = pos - sub_begin;
-                    const uint32_t r = khg_cur_runlen(cur, onebit, end - pos);
-                    if (r) {  // a run of 1-bit codewords: r starts at once
-                        const uint64_t m = khg_mask_range(rel, r);
-                        khg_lds_or(&mask[(rel >> 5) * KHG_DEC_BLOCK], (uint32_t)(m >> 32));
-                        if ((uint32_t)m) khg_lds_or(&mask[((rel >> 5) + 1) * KHG_DEC_BLOCK], (uint32_t)m);
-                        khg_cur_skip(cur, bits, r);
-                        pos += r;
-                        n += r;
-                        continue;
-                    }
+            for (uint32_t w = 0; w < KHG_SUB_WORDS; ++w) mask[w * KHG_DEC_BLOCK] = 0;
+            // each trip: a run of the 1-bit code (possibly empty), then one other codeword
+            while (pos < end) {
+                uint32_t rel = pos - sub_begin;
+                const uint32_t r = khg_cur_runlen(cur, onebit, end - pos);
+                if (r) {  // r codeword starts at once
+                    const uint64_t m = khg_mask_range(rel, r);
+                    khg_lds_or(&mask[(rel >> 5) * KHG_DEC_BLOCK], (uint32_t)(m >> 32));
+                    if ((uint32_t)m) khg_lds_or(&mask[((rel >> 5) + 1) * KHG_DEC_BLOCK], (uint32_t)m);
+                    khg_cur_skip(cur, bits, r);
+                    pos += r;
+                    n += r;
+                    rel += r;
+                }
+                if (pos < end && r < 32) {  // a run cut at 32 may simply go on
                     int s;
                     uint32_t len = khg_cur_decode(cur, bits, sh.lut, lut2, left, right, tsym, &s);
                     if (len == 0) {
@@ -594,50 +590,118 @@ KHG_DEV void khg_dec_map_body(const KhgDecArgs& a, uint32_t blk, KhgDecSmem& sh)
                     pos += len;
                     ++n;
                 }
-                have_main = true;
-            } else {
-                while (pos < end) {
-                    uint32_t rel = pos - sub_begin;
-                    const uint32_t w = rel >> 5;
-                    const uint64_t two = ((uint64_t)mask[w * KHG_DEC_BLOCK] << 32) |
-                                         (w + 1 < KHG_SUB_WORDS ? mask[(w + 1) * KHG_DEC_BLOCK] : 0u);
-                    uint32_t r = khg_cur_runlen(cur, onebit, end - pos);
-                    // codeword starts of this run at the cursor: the run's positions, or just this one
-                    const uint64_t hits = two & khg_mask_range(rel, r ? r : 1);
-                    if (hits) {  // landed on a codeword start of the first run: identical from here on
-                        const uint32_t j = (uint32_t)__builtin_clzll(hits) - (rel & 31);
-                        n += j;
-                        rel += j;
-                        const uint32_t wq = rel >> 5, bit = 0x80000000u >> (rel & 31);
-                        uint32_t rest = (uint32_t)__builtin_popcount(mask[wq * KHG_DEC_BLOCK] & (bit | (bit - 1)));
-                        for (uint32_t w2 = wq + 1; w2 < KHG_SUB_WORDS; ++w2)
-                            rest += (uint32_t)__builtin_popcount(mask[w2 * KHG_DEC_BLOCK]);
-                        n += rest;
-                        joined = true;
+            }
+            if (dead || pos >= nbits) main_arr = KHG_OFF_NONE;
+            else main_arr = pos - (sub_begin + KHG_SUB_BITS);  // pos >= sub_begin + 512, overshoot < M
+            map[oo * KHG_DEC_BLOCK] = khg_map_entry(main_arr, n);
+            have_main = true;
+            break;
+        }
+#ifdef KHG_TIMING
+        if (tid == 0) a.blk[blk].pad_[4] = (uint32_t)wall_clock64();
+#endif
+        //    Every other such run stops as soon as it lands on a recorded start (inside a run of the 1-bit
+        //    code every position is one, so no run handling is needed here).  Runs that do not rejoin --
+        //    a stretch of near-equal code lengths has one per residue -- are long chains of dependent LDS
+        //    lookups, so KHG_RUN_ILP of them advance together, one codeword each per trip, with the
+        //    lookups of all of them issued before any is used.
+        while (have_main) {
+            uint32_t ro[KHG_RUN_ILP], rpos[KHG_RUN_ILP], rn[KHG_RUN_ILP], rjoin[KHG_RUN_ILP];
+            bool ract[KHG_RUN_ILP], rused[KHG_RUN_ILP], rdead[KHG_RUN_ILP];
+            KhgCursor rc[KHG_RUN_ILP];
+            KHG_UNROLL
+            for (int k = 0; k < KHG_RUN_ILP; ++k) {
+                rused[k] = false;
+                ro[k] = 0;
+                rpos[k] = sub_begin;
+                while (oo > 0) {
+                    --oo;
+                    const uint16_t e0 = map[oo * KHG_DEC_BLOCK];
+                    if (khg_map_arr(e0) == KHG_OFF_TEMP && khg_map_cnt(e0) >= M) {
+                        rused[k] = true;
+                        ro[k] = (uint32_t)oo;
+                        rpos[k] = sub_begin + khg_map_cnt(e0);
                         break;
                     }
-                    if (r) {
-                        khg_cur_skip(cur, bits, r);
-                        pos += r;
-                        n += r;
-                        continue;
+                }
+                rn[k] = 1;
+                rjoin[k] = 0xFFFFFFFFu;
+                rdead[k] = false;
+                ract[k] = rused[k] && rpos[k] < end;
+                khg_cur_init(rc[k], bits, ract[k] ? rpos[k] : sub_begin);
+            }
+            if (!rused[0]) break;
+            bool any = false;
+            KHG_UNROLL
+            for (int k = 0; k < KHG_RUN_ILP; ++k) any = any || ract[k];
+            while (any) {
+                uint32_t mw[KHG_RUN_ILP], le[KHG_RUN_ILP], nx[KHG_RUN_ILP], relc[KHG_RUN_ILP];
+                KHG_UNROLL
+                for (int k = 0; k < KHG_RUN_ILP; ++k) {  // all lookups first (a finished run repeats its last ones)
+                    const uint32_t rel = rpos[k] - sub_begin;
+                    relc[k] = rel < KHG_SUB_BITS ? rel : KHG_SUB_BITS - 1;
+                    mw[k] = mask[(relc[k] >> 5) * KHG_DEC_BLOCK];
+                    le[k] = sh.lut[(uint32_t)(rc[k].buf >> (64 - KHG_LUT_BITS))];
+                    nx[k] = bits.stage[khg_stage_slot(rc[k].next)];
+                }
+                any = false;
+                KHG_UNROLL
+                for (int k = 0; k < KHG_RUN_ILP; ++k) {
+                    if (!ract[k]) continue;
+                    const uint32_t len = (le[k] >> 16) & 0xFF;
+                    if ((mw[k] << (relc[k] & 31)) & 0x80000000u) {  // a codeword start of the first run: identical from here on
+                        rjoin[k] = relc[k];
+                        ract[k] = false;
+                    } else if (!(le[k] & 0x80000000u)) {  // longer than the first-level table: the general decoder
+                        int s;
+                        const uint32_t l2 = khg_decode_one(bits, sh.lut, lut2, left, right, tsym, rpos[k], &s);
+                        if (l2 == 0) {
+                            rdead[k] = true;
+                            ract[k] = false;
+                        } else {
+                            rpos[k] += l2;
+                            ++rn[k];
+                            ract[k] = rpos[k] < end;
+                            khg_cur_init(rc[k], bits, ract[k] ? rpos[k] : sub_begin);
+                        }
+                    } else if (rpos[k] + len > nbits) {  // the stream ends inside this codeword
+                        rdead[k] = true;
+                        ract[k] = false;
+                    } else {
+                        KhgCursor& c = rc[k];
+                        c.buf <<= len;
+                        c.avail -= (int)len;
+                        c.pos += len;
+                        if (c.avail <= 32) {
+                            c.buf |= (uint64_t)nx[k] << (32 - c.avail);
+                            c.avail += 32;
+                            c.next++;
+                        }
+                        rpos[k] += len;
+                        ++rn[k];
+                        ract[k] = rpos[k] < end;
                     }
-                    int s;
-                    uint32_t len = khg_cur_decode(cur, bits, sh.lut, lut2, left, right, tsym, &s);
-                    if (len == 0) {
-                        dead = true;
-                        break;
-                    }
-                    pos += len;
-                    ++n;
+                    any = any || ract[k];
                 }
             }
-            uint32_t arr;
-            if (joined) arr = main_arr;
-            else if (dead || pos >= nbits) arr = KHG_OFF_NONE;
-            else arr = pos - (sub_begin + KHG_SUB_BITS);  // pos >= sub_begin + 512, overshoot < M
-            if (is_main) main_arr = arr;
-            map[oo * KHG_DEC_BLOCK] = khg_map_entry(arr, n);
+            KHG_UNROLL
+            for (int k = 0; k < KHG_RUN_ILP; ++k) {
+                if (!rused[k]) continue;
+                uint32_t arr, n = rn[k];
+                if (rjoin[k] != 0xFFFFFFFFu) {
+                    const uint32_t wq = rjoin[k] >> 5, bit = 0x80000000u >> (rjoin[k] & 31);
+                    uint32_t rest = (uint32_t)__builtin_popcount(mask[wq * KHG_DEC_BLOCK] & (bit | (bit - 1)));
+                    for (uint32_t w2 = wq + 1; w2 < KHG_SUB_WORDS; ++w2)
+                        rest += (uint32_t)__builtin_popcount(mask[w2 * KHG_DEC_BLOCK]);
+                    n += rest;
+                    arr = main_arr;
+                } else if (rdead[k] || rpos[k] >= nbits) {
+                    arr = KHG_OFF_NONE;
+                } else {
+                    arr = rpos[k] - (sub_begin + KHG_SUB_BITS);
+                }
+                map[ro[k] * KHG_DEC_BLOCK] = khg_map_entry(arr, n);
+            }
         }
         // 3. the other offsets reuse the entry of the offset their first codeword lands on
         for (uint32_t oo = M; oo-- > 0;) {
@@ -646,6 +710,9 @@ KHG_DEV void khg_dec_map_body(const KhgDecArgs& a, uint32_t blk, KhgDecSmem& sh)
             const uint16_t r = map[khg_map_cnt(e0) * KHG_DEC_BLOCK];  // landing offset > oo: already final
             map[oo * KHG_DEC_BLOCK] = khg_map_entry(khg_map_arr(r), khg_map_cnt(r) + 1);
         }
+#ifdef KHG_TIMING
+        if (tid == 0) a.blk[blk].pad_[5] = (uint32_t)wall_clock64();
+#endif
     }
     KHG_BARRIER();
     KHG_FOR_THREADS(256)
@@ -668,6 +735,12 @@ KHG_DEV void khg_dec_map_body(const KhgDecArgs& a, uint32_t blk, KhgDecSmem& sh)
             }
             a.blk[blk].map[tid] = (off << 24) | tot;
         }
+#ifdef KHG_TIMING
+        if (tid == 0) {  // developer build: workgroup start / end stamps (100 MHz), read back by khg_debug_blocks
+            a.blk[blk].pad_[0] = (uint32_t)tmap0;
+            a.blk[blk].pad_[1] = (uint32_t)wall_clock64();
+        }
+#endif
     }
 }
 
@@ -816,8 +889,10 @@ KHG_DEV void khg_dec_write_body(const KhgDecArgs& a, uint32_t blk, KhgDecWriteSm
             }
         }
 #ifdef KHG_TIMING
-        if ((tid & 63) == 0 && (blk % 37) == 0)
-            printf("write blk %u wave %d start %lld dur %lld (10ns)\n", blk, tid >> 6, tm0, wall_clock64() - tm0);
+        if ((tid & 63) == 0) {
+            a.blk[blk].pad_[2] = (uint32_t)tm0;
+            khg_atomic_max_i((int*)&a.blk[blk].pad_[3], (int)((uint32_t)wall_clock64() - (uint32_t)tm0));
+        }
 #endif
     }
 }

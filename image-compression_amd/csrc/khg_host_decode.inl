@@ -158,3 +158,16 @@ extern "C" int khg_psnr_dev(khg_ctx* c, const uint8_t* d_ir, const uint8_t* d_ig
     *psnr = Mse == 0 ? 100. : 10 * log10(255 * 255 / Mse);
     return KHG_OK;
 }
+
+#ifdef KHG_TIMING
+// Developer build only: the per-workgroup records of the last decode (timing stamps in pad_).
+extern "C" int khg_debug_blocks(khg_ctx* c, void* host, size_t bytes, uint32_t* blk0, uint32_t* nblocks)
+{
+    const KhgDecArgs d = khg_dec_args(c->ws, c->dws, nullptr, 0, c->max_rows, c->max_cols);
+    for (int p = 0; p < 3; ++p) blk0[p] = d.blk0[p];
+    *nblocks = d.nblocks;
+    size_t want = (size_t)d.nblocks * sizeof(KhgBlkInfo);
+    KHG_HIP(hipMemcpy(host, c->dws.blk, want < bytes ? want : bytes, hipMemcpyDeviceToHost));
+    return KHG_OK;
+}
+#endif

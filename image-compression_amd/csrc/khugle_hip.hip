@@ -67,10 +67,21 @@ __global__ __launch_bounds__(256) void khg_dec_tree_kernel(KhgDecArgs a)
     khg_dec_tree_body(a, (int)blockIdx.x, sh);
 }
 
+// Workgroups are dispatched in blockIdx order and the slow ones sit at the start of each plane's stream
+// (the near-fixed-length codes of the LL band need one full run per residue).  Dispatching Cr, Cb, then Y
+// starts every slow workgroup in the first wave of dispatches instead of leaving the chroma ones for last.
+__device__ __forceinline__ uint32_t khg_dec_dispatch_order(const KhgDecArgs& a, uint32_t b)
+{
+    const uint32_t c2 = a.nblocks - a.blk0[2], c1 = a.blk0[2] - a.blk0[1];
+    if (b < c2) return a.blk0[2] + b;
+    if (b < c2 + c1) return a.blk0[1] + (b - c2);
+    return b - c2 - c1;
+}
+
 __global__ __launch_bounds__(256) void khg_dec_map_kernel(KhgDecArgs a)
 {
     __shared__ KhgDecSmem sh;
-    khg_dec_map_body(a, blockIdx.x, sh);
+    khg_dec_map_body(a, khg_dec_dispatch_order(a, blockIdx.x), sh);
 }
 
 __global__ __launch_bounds__(256) void khg_dec_chain_kernel(KhgDecArgs a)
@@ -82,7 +93,7 @@ __global__ __launch_bounds__(256) void khg_dec_chain_kernel(KhgDecArgs a)
 __global__ __launch_bounds__(256) void khg_dec_write_kernel(KhgDecArgs a)
 {
     __shared__ KhgDecWriteSmem sh;
-    khg_dec_write_body(a, blockIdx.x, sh);
+    khg_dec_write_body(a, khg_dec_dispatch_order(a, blockIdx.x), sh);
 }
 
 template <int LEVEL, bool RGB>
