@@ -68,7 +68,7 @@ def _cpu_worker(args):
     return time.perf_counter() - t0, te, td
 
 
-def cpu_baseline(side=2048, frames_per_core=1):
+def cpu_baseline(side=2048, frames_per_core=3):
     import multiprocessing as mp
     import oracle_py as O
     cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
@@ -103,6 +103,8 @@ def main():
     ap.add_argument("--rows", type=int, default=ROWS)
     ap.add_argument("--cols", type=int, default=COLS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--isolated-kernel", action="store_true",
+                    help="also time the dominant kernel alone on an idle GPU (20 extra launches after the timed region)")
     args = ap.parse_args()
 
     import numpy as np
@@ -165,6 +167,8 @@ def main():
     for _ in range(args.warmup):
         encode_pass()
         decode_pass()
+    for c in ctxs:
+        c.profile_luma_forward(True)  # HIP events around the dominant kernel, on the stream it is launched on
     barrier()
     t_enc = t_dec = 0.0
     t0 = time.perf_counter()
@@ -185,10 +189,16 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     elapsed, t_enc, t_dec = [float(x) for x in tt.cpu()]
 
-    # dominant kernel, timed live with HIP events on the stream it is launched on
-    with torch.cuda.stream(streams[0]):
-        k_ms = ctxs[0].time_luma_forward_dev(frames[0], LVL, reps=20)
+    # dominant kernel: average duration of its launches inside the timed region (other streams' kernels share
+    # the GPU with it there), from the events khg_encode_dev recorded around each launch
+    prof = [c.profile_read() for c in ctxs]
+    k_launches = sum(n for _, n in prof)
+    k_ms = sum(ms for ms, _ in prof) / max(1, k_launches)
     achieved = LUMA_FWD_BYTES_PER_PX * px / (k_ms * 1e-3) / 1e9
+    k_alone_ms = None
+    if args.isolated_kernel:
+        with torch.cuda.stream(streams[0]):
+            k_alone_ms = ctxs[0].time_luma_forward_dev(frames[0], LVL, reps=20)
 
     if rank == 0:
         # parity spot check (untimed): the last frame's bytes and pixels against the CPU oracle
@@ -235,7 +245,9 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "khg_fwd_kernel<0,1> (colour + DWT level 1 + quantiser + histogram, luma)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "bytes_per_launch": LUMA_FWD_BYTES_PER_PX * px, "avg_launch_ms": round(k_ms, 4)},
+                         "bytes_per_launch": LUMA_FWD_BYTES_PER_PX * px, "avg_launch_ms": round(k_ms, 4),
+                         "launches_timed": k_launches,
+                         "alone_launch_ms": None if k_alone_ms is None else round(k_alone_ms, 4)},
             "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)

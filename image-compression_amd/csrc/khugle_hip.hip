@@ -144,6 +144,10 @@ struct khg_ctx {
     double* ssim_blocks; // per-block SSIM values
     double* h_ssim_blocks;
     unsigned long long* sse; // [3] sums of squared errors
+    // optional timing of the luma forward launch inside khg_encode_dev (khg_profile_luma_forward)
+    int prof_on, prof_pending, prof_launches;
+    double prof_ms;
+    hipEvent_t prof_e0, prof_e1;
 };
 
 static size_t khg_align(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -237,6 +241,8 @@ extern "C" void khg_ctx_destroy(khg_ctx* c)
     if (c->h_res) (void)hipHostFree(c->h_res);
     if (c->h_ssim_blocks) (void)hipHostFree(c->h_ssim_blocks);
     if (c->done) (void)hipEventDestroy(c->done);
+    if (c->prof_e0) (void)hipEventDestroy(c->prof_e0);
+    if (c->prof_e1) (void)hipEventDestroy(c->prof_e1);
     delete c;
 }
 
@@ -256,6 +262,41 @@ static void khg_launch_fwd(const KhgFwdArgs& a, const KhgFwdGrid& g, hipStream_t
 }
 
 // Colour + both DWT levels + quantiser + histograms for the three components.
+// Adds the finished luma forward launch's event-to-event time to the context's tally.
+static void khg_profile_collect(khg_ctx* c)
+{
+    if (!c->prof_pending) return;
+    c->prof_pending = 0;
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, c->prof_e0, c->prof_e1) == hipSuccess) {
+        c->prof_ms += ms;
+        c->prof_launches++;
+    }
+}
+
+extern "C" int khg_profile_luma_forward(khg_ctx* c, int enable)
+{
+    if (!c) return KHG_ERR_ARG;
+    KHG_HIP(hipSetDevice(c->device));
+    if (enable && !c->prof_e0) {
+        KHG_HIP(hipEventCreate(&c->prof_e0));
+        KHG_HIP(hipEventCreate(&c->prof_e1));
+    }
+    c->prof_on = enable != 0;
+    c->prof_ms = 0;
+    c->prof_launches = 0;
+    c->prof_pending = 0;
+    return KHG_OK;
+}
+
+extern "C" int khg_profile_read(khg_ctx* c, double* total_ms, int* launches)
+{
+    if (!c || !total_ms || !launches) return KHG_ERR_ARG;
+    *total_ms = c->prof_ms;
+    *launches = c->prof_launches;
+    return KHG_OK;
+}
+
 static int khg_enqueue_forward(khg_ctx* c, const uint8_t* r, const uint8_t* g, const uint8_t* b, int rows, int cols,
                                int lvl, double* const coef[3], hipStream_t st)
 {
@@ -266,7 +307,12 @@ static int khg_enqueue_forward(khg_ctx* c, const uint8_t* r, const uint8_t* g, c
     KhgFwdGrid gr;
     KhgFwdArgs a;
     a = khg_fwd_args(ws, r, g, b, rows, cols, lvl, 0, 1, coef ? coef[0] : nullptr, &gr);
+    if (c->prof_on) KHG_HIP(hipEventRecord(c->prof_e0, st));
     khg_launch_fwd<KHG_SRC_Y, 1>(a, gr, st);
+    if (c->prof_on) {
+        KHG_HIP(hipEventRecord(c->prof_e1, st));
+        c->prof_pending = 1;
+    }
     a = khg_fwd_args(ws, r, g, b, rows, cols, lvl, 1, 1, coef ? coef[1] : nullptr, &gr);
     khg_launch_fwd<KHG_SRC_CB, 1>(a, gr, st);
     a = khg_fwd_args(ws, r, g, b, rows, cols, lvl, 2, 1, coef ? coef[2] : nullptr, &gr);
@@ -311,6 +357,7 @@ extern "C" int khg_encode_result(khg_ctx* c, size_t* out_len)
     if (c->pending != 1) return KHG_ERR_ARG;
     KHG_HIP(hipEventSynchronize(c->done));
     c->pending = 0;
+    khg_profile_collect(c);
     if (out_len) *out_len = (size_t)c->h_res->total_len;
     return c->h_res->status;
 }

@@ -109,6 +109,17 @@ class Codec:
                                       _ptr(qcb), _ptr(qcr), _stream()), "symbols")
         return qy, qcb, qcr
 
+    def profile_luma_forward(self, enable=True):
+        """Start (or stop) timing the luma forward launch inside encode_dev with HIP events; resets the tally."""
+        _check(self.L.khg_profile_luma_forward(self._ctx, 1 if enable else 0), "profile_luma_forward")
+
+    def profile_read(self):
+        """(sum of milliseconds, launches) collected since profile_luma_forward()."""
+        ms = C.c_double(0)
+        n = C.c_int(0)
+        _check(self.L.khg_profile_read(self._ctx, C.byref(ms), C.byref(n)), "profile_read")
+        return ms.value, n.value
+
     def time_luma_forward_dev(self, rgb, lvl, reps=10):
         """Mean duration (ms) of the level-1 luma forward kernel, HIP events on the current stream."""
         _, h, w = rgb.shape

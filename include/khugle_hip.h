@@ -106,6 +106,12 @@ int khg_symbols_dev(khg_ctx *ctx, const uint8_t *d_r, const uint8_t *d_g, const 
 int khg_time_luma_forward_dev(khg_ctx *ctx, const uint8_t *d_r, const uint8_t *d_g, const uint8_t *d_b, int rows,
                               int cols, int lvl, int reps, float *avg_ms, void *stream);
 
+/* Measurement aid: while enabled, khg_encode_dev brackets its luma level-1 forward launch with HIP events on
+ * the caller's stream; khg_encode_result adds the elapsed time to a per-context tally that khg_profile_read
+ * returns (sum of milliseconds, number of launches).  Enabling or disabling resets the tally. */
+int khg_profile_luma_forward(khg_ctx *ctx, int enable);
+int khg_profile_read(khg_ctx *ctx, double *total_ms, int *launches);
+
 /* ---- synthetic frames for benchmarks: deterministic integer arithmetic, identical to
  * khugle_amd.synth.synth_frame on the host.  Device planes. */
 int khg_synth_dev(uint8_t *d_r, uint8_t *d_g, uint8_t *d_b, int rows, int cols, uint32_t seed, uint32_t index,
