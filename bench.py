@@ -111,6 +111,7 @@ def main():
     import torch
     import torch.distributed as dist
     import khugle_amd
+    from khugle_amd.shard import frame_range, max_over_ranks, whole_job_rate
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -129,8 +130,8 @@ def main():
     streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
     # inputs resident in HBM before the timed region: frames rank*F .. rank*F+F-1 of the synthetic batch
     frames = torch.empty((F, 3, rows, cols), dtype=torch.uint8, device=dev)
-    for f in range(F):
-        ctxs[0].synth_dev(rows, cols, SEED, rank * F + f, out=frames[f])
+    for f, g in enumerate(frame_range(rank, world, F)):
+        ctxs[0].synth_dev(rows, cols, SEED, g, out=frames[f])
     cap = (2 * px + (1 << 20)) & ~3  # 2 bytes per pixel: ~7x the High-preset size, checked by the encoder
     comps = torch.zeros((F, cap), dtype=torch.uint8, device=dev)
     decs = torch.empty((S, 3, rows, cols), dtype=torch.uint8, device=dev)
@@ -184,10 +185,7 @@ def main():
         t_dec += c - b
     barrier()
     elapsed = time.perf_counter() - t0
-    tt = torch.tensor([elapsed, t_enc, t_dec], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    elapsed, t_enc, t_dec = [float(x) for x in tt.cpu()]
+    elapsed, t_enc, t_dec = max_over_ranks([elapsed, t_enc, t_dec], dev)
 
     # dominant kernel: average duration of its launches inside the timed region (other streams' kernels share
     # the GPU with it there), from the events khg_encode_dev recorded around each launch
@@ -224,7 +222,7 @@ def main():
         bpp = 8.0 * sum(lens) / (F * px)
         line = {
             "metric": "encode+decode megapixels/sec (node), 8K batch, High preset",
-            "value": round(total_mp / elapsed, 1),
+            "value": round(whole_job_rate(world, F, args.steps, px, elapsed), 1),
             "unit": "MP/s",
             "n_gpus": world,
             "steps": args.steps,
