@@ -545,8 +545,9 @@ KHG_DEV void khg_pack_body(const KhgEncArgs& a, uint32_t chunk, KhgPackSmem& sh)
                 uint64_t v = c << (64 - len);  // left-aligned code (bits above len fall off)
                 uint32_t w = pos >> 5, sh_ = pos & 31;
                 uint32_t hi = (uint32_t)(v >> 32), lo = (uint32_t)v;
-                khg_atomic_or(&sh.words[w], hi >> sh_);
-                if (sh_ + len > 32) {
+                // an all-zero code (normally the most frequent symbol's 1-bit code) sets nothing
+                if (hi >> sh_) khg_atomic_or(&sh.words[w], hi >> sh_);
+                if (v != 0 && sh_ + len > 32) {
                     uint32_t mid = sh_ ? (hi << (32 - sh_)) | (lo >> sh_) : lo;
                     khg_atomic_or(&sh.words[w + 1], mid);
                     if (sh_ + len > 64) khg_atomic_or(&sh.words[w + 2], lo << (32 - sh_));

@@ -74,27 +74,51 @@ KHG_DEV void khg_inv_step(KhgILift& st, double lo, double hi, double& xe, double
     st.s0 = s0n;
 }
 
-// Coefficient at packed position (yo, xo) of the plane being inverted.
+// Raw inputs of one thread's column for one batch: symbols as stored, LL values as f64.  Fetched one batch
+// ahead (khg_inv_fetch) so the loads fly during the row phase, turned into coefficients when the column phase
+// consumes them (khg_inv_coef).
+struct KhgInvRaw {
+    int q[2 * KHG_IBATCH];     // [2s] low-pass row of pair s, [2s+1] its high-pass row
+    double ll[KHG_IBATCH];     // level 1, low-pass row of a left-half column: the LL sample instead of a symbol
+};
+
+// Band of packed position (yo, xo), -1 for the level-1 LL quadrant.
 template <int LEVEL>
-KHG_DEV double khg_inv_load(const KhgInvArgs& a, const KhgQuant& qc, int lvl, int yo, int xo, int hh, int hw)
+KHG_DEV int khg_inv_band(int yo, int xo, int hh, int hw)
 {
-    int band;
-    if (LEVEL == 2) {
-        band = (yo >= hh ? 2 : 0) + (xo >= hw ? 1 : 0);
-    } else {
-        if (yo < hh && xo < hw) return a.ll[(size_t)yo * a.ll_pitch + xo];
-        band = yo < hh ? 4 : (xo < hw ? 5 : 6);
-    }
-    int q = a.sym[(size_t)yo * a.sym_pitch + xo];
-    return (double)q * khg_divisor(qc, band, xo, yo, lvl);  // Decompress.h:105, 120-121
+    if (LEVEL == 2) return (yo >= hh ? 2 : 0) + (xo >= hw ? 1 : 0);
+    if (yo < hh && xo < hw) return -1;
+    return yo < hh ? 4 : (xo < hw ? 5 : 6);
 }
 
-KHG_DEV uint8_t khg_clamp_u8(double v)
+template <int LEVEL>
+KHG_DEV void khg_inv_fetch(const KhgInvArgs& a, KhgInvRaw& raw, int s, int ye, int yo, int xo, int hh, int hw)
 {
-    // max(0, min(v, 255)) with the Win32 macros (a<b?a:b), (a>b?a:b), then truncation to unsigned char
-    double m = (v < 255.0) ? v : 255.0;
-    double c = (0.0 > m) ? 0.0 : m;
-    return (uint8_t)c;
+    if (khg_inv_band<LEVEL>(ye, xo, hh, hw) < 0) {
+        raw.ll[s] = a.ll[(size_t)ye * a.ll_pitch + xo];
+        raw.q[2 * s] = 0;
+    } else {
+        raw.ll[s] = 0.0;
+        raw.q[2 * s] = a.sym[(size_t)ye * a.sym_pitch + xo];
+    }
+    raw.q[2 * s + 1] = a.sym[(size_t)yo * a.sym_pitch + xo];
+}
+
+// Decompress.h:105, 120-121: coefficient = symbol * divisor of its band and position.
+template <int LEVEL>
+KHG_DEV double khg_inv_coef(const KhgQuant& qc, int lvl, int q, double ll, int y, int xo, int hh, int hw)
+{
+    const int band = khg_inv_band<LEVEL>(y, xo, hh, hw);
+    if (band < 0) return ll;
+    return (double)q * khg_divisor(qc, band, xo, y, lvl);
+}
+
+KHG_DEV uint32_t khg_clamp_u8(double v)
+{
+    // Main.cpp:307-315: max(0, min(v, 255)) with the Win32 macros (a<b?a:b), (a>b?a:b), then truncation to
+    // unsigned char.  v is never NaN here (finite symbols times finite constants), and for every other v
+    // fmin/fmax pick the same operand as the macros, up to the sign of a zero that the truncation drops.
+    return (uint32_t)fmax(0.0, fmin(v, 255.0));
 }
 
 // Colorspace.h:25-36 + Main.cpp:307-315 for the two pixels that share one chroma site: products and sums
@@ -123,11 +147,26 @@ KHG_DEV void khg_inv_strip_body(const KhgInvArgs& a, int bid, KhgInvSmem& sh)
     const int lvl = a.hdr->lvl;
     const KhgQuant& qc = a.q[lvl];
 
+    // The RGB variant's row phase is register-hungry; holding a prefetched batch on top would cost it a wave
+    // per SIMD, which hurts more than the prefetch helps, so it loads at the start of the column phase.
+    const bool PREFETCH = !RGB;
     KhgILift cs[KHG_NSLOT(256)];
+    KhgInvRaw raws[KHG_NSLOT(256)];
     KHG_FOR_THREADS(256)
     {
         KhgILift z = {0, 0, 0, 0};
         cs[KHG_SLOT] = z;
+        if (PREFETCH && tid < KHG_ICOLS) {  // inputs of the first batch
+            const int half = tid >= KHG_IHALF, tt = half ? tid - KHG_IHALF : tid;
+            const int rx = khg_reflect(2 * ((x0 >> 1) - 2 + tt) + half, a.pw);
+            const int xo = (rx >> 1) + (half ? hw : 0);
+            KHG_UNROLL
+            for (int s = 0; s < KHG_IBATCH; ++s) {
+                int j = k0 - 2 + s;
+                khg_inv_fetch<LEVEL>(a, raws[KHG_SLOT], s, khg_reflect(2 * j, a.ph) >> 1,
+                                     hh + (khg_reflect(2 * j + 1, a.ph) >> 1), xo, hh, hw);
+            }
+        }
     }
     for (int b = 0; b < nb; ++b) {
         KHG_FOR_THREADS(256)
@@ -138,24 +177,36 @@ KHG_DEV void khg_inv_strip_body(const KhgInvArgs& a, int bid, KhgInvSmem& sh)
                 const int rx = khg_reflect(2 * ((x0 >> 1) - 2 + tt) + half, a.pw);  // natural column, parity = half
                 const int xo = (rx >> 1) + (half ? hw : 0);
                 KhgILift st = cs[KHG_SLOT];
-                // all loads of the batch first (independent, so their latencies overlap), then the lifting chain
-                double lo[KHG_IBATCH], hi[KHG_IBATCH];
+                KhgInvRaw& raw = raws[KHG_SLOT];
+                if (!PREFETCH) {  // all loads of the batch first (independent), then the lifting chain
+                    KHG_UNROLL
+                    for (int s = 0; s < KHG_IBATCH; ++s) {
+                        int j = k0 - 2 + b * KHG_IBATCH + s;
+                        khg_inv_fetch<LEVEL>(a, raw, s, khg_reflect(2 * j, a.ph) >> 1,
+                                             hh + (khg_reflect(2 * j + 1, a.ph) >> 1), xo, hh, hw);
+                    }
+                }
                 KHG_UNROLL
                 for (int s = 0; s < KHG_IBATCH; ++s) {
                     int j = k0 - 2 + b * KHG_IBATCH + s;  // row pair fed in this step
                     int ye = khg_reflect(2 * j, a.ph) >> 1;
                     int yo = hh + (khg_reflect(2 * j + 1, a.ph) >> 1);
-                    lo[s] = khg_inv_load<LEVEL>(a, qc, lvl, ye, xo, hh, hw);
-                    hi[s] = khg_inv_load<LEVEL>(a, qc, lvl, yo, xo, hh, hw);
-                }
-                KHG_UNROLL
-                for (int s = 0; s < KHG_IBATCH; ++s) {
+                    double lo = khg_inv_coef<LEVEL>(qc, lvl, raw.q[2 * s], raw.ll[s], ye, xo, hh, hw);
+                    double hi = khg_inv_coef<LEVEL>(qc, lvl, raw.q[2 * s + 1], 0.0, yo, xo, hh, hw);
                     double xe, xod;
-                    khg_inv_step(st, lo[s], hi[s], xe, xod);
+                    khg_inv_step(st, lo, hi, xe, xod);
                     sh.T[(2 * s) * KHG_T_PITCH + tid] = xe;
                     sh.T[(2 * s + 1) * KHG_T_PITCH + tid] = xod;
                 }
                 cs[KHG_SLOT] = st;
+                if (PREFETCH && b + 1 < nb) {  // next batch's inputs: in flight during the row phase
+                    KHG_UNROLL
+                    for (int s = 0; s < KHG_IBATCH; ++s) {
+                        int j = k0 - 2 + (b + 1) * KHG_IBATCH + s;
+                        khg_inv_fetch<LEVEL>(a, raw, s, khg_reflect(2 * j, a.ph) >> 1,
+                                             hh + (khg_reflect(2 * j + 1, a.ph) >> 1), xo, hh, hw);
+                    }
+                }
             }
         }
         KHG_BARRIER();

@@ -96,8 +96,10 @@ __global__ __launch_bounds__(256) void khg_dec_write_kernel(KhgDecArgs a)
     khg_dec_write_body(a, khg_dec_dispatch_order(a, blockIdx.x), sh);
 }
 
+// 32 KB of LDS allows 5 workgroups per CU = 5 waves per SIMD; the bound keeps the register count (<= 96) from
+// being what limits it instead (the kernel is latency-bound: 4 waves instead of 5 cost 30 %).
 template <int LEVEL, bool RGB>
-__global__ __launch_bounds__(256) void khg_inv_kernel(KhgInvArgs a)
+__global__ __launch_bounds__(256, 5) void khg_inv_kernel(KhgInvArgs a)
 {
     __shared__ KhgInvSmem sh;
     khg_inv_strip_body<LEVEL, RGB>(a, (int)blockIdx.x, sh);
