@@ -19,8 +19,6 @@ enum { KHG_SRC_Y = 0, KHG_SRC_CB = 1, KHG_SRC_CR = 2, KHG_SRC_PLANE = 3 };
 
 enum {
     KHG_B_PITCH = KHG_STRIP + 1,  // odd pitch: conflict-free ds_write_b64 across the 16 rows of a wave
-    KHG_LHIST = 1024,            // LDS histogram covers symbols [-512, 511]
-    KHG_LHIST_BIAS = 512,
     KHG_MAX_SEG_ROWS = 128,      // rows per workgroup segment, at most
     KHG_RD_N = KHG_STRIP / 2 + KHG_MAX_SEG_ROWS / 2  // reciprocal-divisor entries per band
 };
@@ -46,11 +44,16 @@ struct KhgFwdArgs {
     KhgQuant q;
 };
 
+// LDS of one workgroup.  Level 1 emits detail bands only (small symbols, three bands): a 256-bin histogram and
+// three reciprocal tables keep it under 40 KB, i.e. four workgroups per CU.  Level 2 also emits the LL band,
+// whose symbols spread over hundreds of values: 1024 bins, four tables.
+template <int LEVEL>
 struct KhgFwdSmem {
+    enum { LHIST = LEVEL == 1 ? 256 : 1024, LHIST_BIAS = LHIST / 2, NBAND = LEVEL == 1 ? 3 : 4 };
     double B[KHG_BATCH * KHG_B_PITCH];
-    uint32_t cnt[KHG_LHIST];
-    uint32_t first[KHG_LHIST];
-    double rdiv[4 * KHG_RD_N];  // 1/divisor of band slot s at diagonal u: [s * KHG_RD_N + u]
+    uint32_t cnt[LHIST];    // symbols [-LHIST/2, LHIST/2)
+    uint32_t first[LHIST];
+    double rdiv[NBAND * KHG_RD_N];  // 1/divisor of band slot s at diagonal u: [s * KHG_RD_N + u]
 };
 
 // Streaming state of one 1-D lifting line: values of pair j-1 (e, o, d1, s1) and d2 of pair j-2.
@@ -204,7 +207,8 @@ struct KhgHot {
 
 // Quantise one coefficient, store the symbol and count it (Compress.h:218-219, Huffman.h:110-139).
 // rdiv = RN(1/divisor) of this position (khg_round_quot_fast); stream 0 = rows k, 1 = rows hh+k.
-KHG_DEV void khg_quant_store(const KhgFwdArgs& a, KhgFwdSmem& sh, KhgHot& hot, double c, double rdiv, int band,
+template <class SMEM>
+KHG_DEV void khg_quant_store(const KhgFwdArgs& a, SMEM& sh, KhgHot& hot, double c, double rdiv, int band,
                              int stream, int y, int x)
 {
     double n;
@@ -216,7 +220,7 @@ KHG_DEV void khg_quant_store(const KhgFwdArgs& a, KhgFwdSmem& sh, KhgHot& hot, d
     int q = (int)n;
     uint32_t raster = (uint32_t)y * (uint32_t)a.sym_pitch + (uint32_t)x;
     a.sym[raster] = (int16_t)q;
-    int l = q + KHG_LHIST_BIAS;
+    int l = q + SMEM::LHIST_BIAS;
     if ((unsigned)(q + 1) <= 2u) {
         hot.cnt += 1ull << (21 * (q + 1));
         uint32_t bit = 1u << (2 * (q + 1) + stream);
@@ -224,7 +228,7 @@ KHG_DEV void khg_quant_store(const KhgFwdArgs& a, KhgFwdSmem& sh, KhgHot& hot, d
             hot.seen |= bit;
             khg_atomic_min(&sh.first[l], raster);
         }
-    } else if ((unsigned)l < (unsigned)KHG_LHIST) {
+    } else if ((unsigned)l < (unsigned)SMEM::LHIST) {
         khg_atomic_add(&sh.cnt[l], 1u);
         khg_atomic_min(&sh.first[l], raster);
     } else {
@@ -235,7 +239,7 @@ KHG_DEV void khg_quant_store(const KhgFwdArgs& a, KhgFwdSmem& sh, KhgHot& hot, d
 
 // LEVEL 1: bands LH(4) HL(5) HH(6) are final, LL feeds level 2.  LEVEL 2: bands 0..3 (Compress.h:154-160).
 template <int SRC, int LEVEL>
-KHG_DEV void khg_fwd_strip_body(const KhgFwdArgs& a, int bid, KhgFwdSmem& sh)
+KHG_DEV void khg_fwd_strip_body(const KhgFwdArgs& a, int bid, KhgFwdSmem<LEVEL>& sh)
 {
     const int strip = bid % a.nstrip, seg = bid / a.nstrip;
     const int x0 = strip * KHG_STRIP;
@@ -257,17 +261,16 @@ KHG_DEV void khg_fwd_strip_body(const KhgFwdArgs& a, int bid, KhgFwdSmem& sh)
         hots[KHG_SLOT] = hz;
         // window of the first batch (row-phase mapping: row tid & 15, run tid >> 4)
         khg_fwd_fetch<SRC>(a, raws[KHG_SLOT], khg_reflect(rin0 + (tid & 15), a.ph), x0 + (tid >> 4) * 16 - 4);
-        for (int i = tid; i < KHG_LHIST; i += 256) {
+        for (int i = tid; i < KhgFwdSmem<LEVEL>::LHIST; i += 256) {
             sh.cnt[i] = 0;
             sh.first[i] = 0xFFFFFFFFu;
         }
         // The divisor depends on the band and on x + y only (Compress.h:215-218); column c of the strip at
         // row pair k sits on diagonal u = c/2 + (k - k0) of each band this workgroup emits.
         const int nu = KHG_STRIP / 2 + (k1 - k0);
-        for (int e = tid; e < 4 * nu; e += 256) {
+        for (int e = tid; e < KhgFwdSmem<LEVEL>::NBAND * nu; e += 256) {
             int s = e / nu, u = e - s * nu;
             int band = LEVEL == 1 ? 4 + s : s;
-            if (band > 6) break;
             int by = (LEVEL == 1 ? (band >= 5) : (band >= 2)) ? hh : 0;
             int bx = (LEVEL == 1 ? (band != 5) : (band & 1)) ? hw : 0;
             sh.rdiv[s * KHG_RD_N + u] = 1.0 / khg_divisor(a.q, band, bx + (x0 >> 1) + u, by + k0, a.lvl);
@@ -351,16 +354,16 @@ KHG_DEV void khg_fwd_strip_body(const KhgFwdArgs& a, int bid, KhgFwdSmem& sh)
         const KhgHot hot = hots[KHG_SLOT];
         for (int v = 0; v < 3; ++v) {
             uint32_t c = (uint32_t)(hot.cnt >> (21 * v)) & 0x1FFFFFu;
-            if (c) khg_atomic_add(&sh.cnt[KHG_LHIST_BIAS - 1 + v], c);
+            if (c) khg_atomic_add(&sh.cnt[KhgFwdSmem<LEVEL>::LHIST_BIAS - 1 + v], c);
         }
     }
     KHG_BARRIER();
     KHG_FOR_THREADS(256)
     {
-        for (int i = tid; i < KHG_LHIST; i += 256) {
+        for (int i = tid; i < KhgFwdSmem<LEVEL>::LHIST; i += 256) {
             uint32_t c = sh.cnt[i];
             if (c) {
-                int bin = i - KHG_LHIST_BIAS + KHG_SYM_BIAS;
+                int bin = i - KhgFwdSmem<LEVEL>::LHIST_BIAS + KHG_SYM_BIAS;
                 khg_atomic_add(&a.hist_cnt[bin], c);
                 khg_atomic_min(&a.hist_first[bin], sh.first[i]);
             }

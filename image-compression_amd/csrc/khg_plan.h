@@ -120,10 +120,11 @@ static inline KhgFwdGrid khg_strip_grid(int ph, int nstrip, int slots, int halo,
     return g;
 }
 
-// Forward transform: 3 workgroups per CU (LDS), 256 CUs; the reciprocal-divisor table caps the rows.
-static inline KhgFwdGrid khg_fwd_grid(int ph, int pw)
+// Forward transform: 4 (level 1) or 3 (level 2) workgroups per CU by LDS, 256 CUs; the reciprocal-divisor
+// table caps the rows.
+static inline KhgFwdGrid khg_fwd_grid(int ph, int pw, int level)
 {
-    return khg_strip_grid(ph, (pw + KHG_STRIP - 1) / KHG_STRIP, 768, 8, KHG_MAX_SEG_ROWS);
+    return khg_strip_grid(ph, (pw + KHG_STRIP - 1) / KHG_STRIP, level == 1 ? 1024 : 768, 8, KHG_MAX_SEG_ROWS);
 }
 
 // Forward-transform arguments of colour component comp (0 Y, 1 Cb, 2 Cr) at level 1 or 2.
@@ -155,7 +156,7 @@ static inline KhgFwdArgs khg_fwd_args(const KhgWorkspace& ws, const uint8_t* r, 
     a.status = &ws.res->status;
     a.lvl = lvl;
     khg_make_quant(rows, cols, lvl, comp != 0, &a.q);
-    *grid = khg_fwd_grid(a.ph, a.pw);
+    *grid = khg_fwd_grid(a.ph, a.pw, level);
     a.seg_rows = grid->seg_rows;
     a.nstrip = grid->nstrip;
     return a;

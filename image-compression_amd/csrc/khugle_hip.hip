@@ -15,10 +15,12 @@
 
 // ------------------------------------------------------------------ kernels
 
+// LDS allows 4 workgroups per CU at level 1 and 3 at level 2; the register bound matches (the kernels are
+// issue- and latency-bound, so resident waves are what they need).
 template <int SRC, int LEVEL>
-__global__ __launch_bounds__(256) void khg_fwd_kernel(KhgFwdArgs a)
+__global__ __launch_bounds__(256, LEVEL == 1 ? 4 : 3) void khg_fwd_kernel(KhgFwdArgs a)
 {
-    __shared__ KhgFwdSmem sh;
+    __shared__ KhgFwdSmem<LEVEL> sh;
     khg_fwd_strip_body<SRC, LEVEL>(a, (int)blockIdx.x, sh);
 }
 

@@ -47,7 +47,7 @@ struct SimWs {
 
 template <int SRC, int LEVEL>
 void run_fwd(const KhgFwdArgs& a, const KhgFwdGrid& g) {
-    KhgFwdSmem* sh = new KhgFwdSmem;
+    KhgFwdSmem<LEVEL>* sh = new KhgFwdSmem<LEVEL>;
     for (int bid = 0; bid < g.nstrip * g.nseg; ++bid) khg_fwd_strip_body<SRC, LEVEL>(a, bid, *sh);
     delete sh;
 }
