@@ -99,13 +99,20 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--frames", type=int, default=128, help="frames per GPU per step")
-    ap.add_argument("--streams", type=int, default=8, help="contexts/streams in flight per GPU")
+    ap.add_argument("--streams", type=int, default=24, help="contexts/streams in flight per GPU")
     ap.add_argument("--rows", type=int, default=ROWS)
     ap.add_argument("--cols", type=int, default=COLS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--isolated-kernel", action="store_true",
-                    help="also time the dominant kernel alone on an idle GPU (20 extra launches after the timed region)")
+    ap.add_argument("--no-square", action="store_true", help="skip the short 5760x5760 pass")
+    ap.add_argument("--no-isolated-kernel", action="store_true",
+                    help="skip timing the dominant kernel alone on an idle GPU (20 launches after the timed region)")
+    ap.add_argument("--hw-queues", type=int, default=0,
+                    help="HIP hardware queues for this process (GPU_MAX_HW_QUEUES); 0 = one per stream, at most 16")
     args = ap.parse_args()
+    # Streams that share a hardware queue run their kernels strictly one after another, single-workgroup
+    # table/tree kernels included; with a queue per stream those hide behind other frames' wide kernels.
+    # Read by the HIP runtime when it initialises, so it is set before torch is imported.
+    os.environ["GPU_MAX_HW_QUEUES"] = str(max(1, min(16, args.hw_queues or args.streams)))
 
     import numpy as np
     import torch
@@ -190,13 +197,61 @@ def main():
     # dominant kernel: average duration of its launches inside the timed region (other streams' kernels share
     # the GPU with it there), from the events khg_encode_dev recorded around each launch
     prof = [c.profile_read() for c in ctxs]
-    k_launches = sum(n for _, n in prof)
-    k_ms = sum(ms for ms, _ in prof) / max(1, k_launches)
+    k_launches = sum(n for _, _, n in prof)
+    k_event_ms = sum(ms for ms, _, _ in prof) / max(1, k_launches)
+    k_ms = sum(dv for _, dv, _ in prof) / max(1, k_launches)
     achieved = LUMA_FWD_BYTES_PER_PX * px / (k_ms * 1e-3) / 1e9
     k_alone_ms = None
-    if args.isolated_kernel:
+    if not args.no_isolated_kernel:
         with torch.cuda.stream(streams[0]):
             k_alone_ms = ctxs[0].time_luma_forward_dev(frames[0], LVL, reps=20)
+
+    # the same generator on a square 8K-class frame (5760 x 5760 = 33.2 MP): the shape the reference itself can
+    # round-trip, so this rate is the one whose small siblings are byte-checked against the reference's files
+    square = None
+    if not args.no_square:
+        side, SF, SS = 5760, 32, min(8, S)
+        sctx = [khugle_amd.Codec(side, side, device=local_rank) for _ in range(SS)]
+        sfr = torch.empty((SF, 3, side, side), dtype=torch.uint8, device=dev)
+        for f, g in enumerate(frame_range(rank, world, SF)):
+            sctx[0].synth_dev(side, side, SEED, g, out=sfr[f])
+        scomp = torch.zeros((SF, (2 * side * side + (1 << 20)) & ~3), dtype=torch.uint8, device=dev)
+        sdec = torch.empty((SS, 3, side, side), dtype=torch.uint8, device=dev)
+        slen = [0] * SF
+        torch.cuda.synchronize()  # frames and buffers were filled on the default stream
+
+        def square_pass():
+            for f in range(SF):
+                c = f % SS
+                if f >= SS:
+                    slen[f - SS] = sctx[c].encode_result()
+                with torch.cuda.stream(streams[c]):
+                    sctx[c].encode_dev(sfr[f], LVL, scomp[f])
+            for f in range(max(0, SF - SS), SF):
+                slen[f] = sctx[f % SS].encode_result()
+            for f in range(SF):
+                c = f % SS
+                if f >= SS:
+                    st_ = sctx[c].last_status()
+                    if st_ != 0:
+                        raise RuntimeError("decode of square frame %d failed: status %d" % (f - SS, st_))
+                with torch.cuda.stream(streams[c]):
+                    sctx[c].decode_dev(scomp[f], slen[f], side, side, sdec[c])
+            for c in range(SS):
+                st_ = sctx[c].last_status()
+                if st_ != 0:
+                    raise RuntimeError("decode of a square frame failed: status %d" % st_)
+
+        square_pass()
+        barrier()
+        ts = time.perf_counter()
+        square_pass()
+        barrier()
+        st, = max_over_ranks([time.perf_counter() - ts], dev)
+        square = {"workload": "%d frames of %dx%d per GPU, same generator and preset, %d streams, one pass"
+                              % (SF, side, side, SS),
+                  "value": round(whole_job_rate(world, SF, 1, side * side, st), 1), "unit": "MP/s"}
+        del sctx, sfr, scomp, sdec
 
     if rank == 0:
         # parity spot check (untimed): the last frame's bytes and pixels against the CPU oracle
@@ -245,8 +300,24 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "bytes_per_launch": LUMA_FWD_BYTES_PER_PX * px, "avg_launch_ms": round(k_ms, 4),
                          "launches_timed": k_launches,
-                         "alone_launch_ms": None if k_alone_ms is None else round(k_alone_ms, 4)},
+                         "event_avg_launch_ms": round(k_event_ms, 4),
+                         "note": "avg_launch_ms: execution span (first workgroup start to last workgroup end, device "
+                                 "clock) of the launches inside the timed region, where the kernel shares the GPU "
+                                 "with the other streams' kernels -- the duration a profiler reports; "
+                                 "event_avg_launch_ms: HIP events around the same launches, which also count the "
+                                 "wait for the GPU; `alone`: the same kernel on an idle GPU (HIP events)",
+                         "alone": None if k_alone_ms is None else {
+                             "avg_launch_ms": round(k_alone_ms, 4),
+                             "achieved": round(LUMA_FWD_BYTES_PER_PX * px / (k_alone_ms * 1e-3) / 1e9, 1),
+                             "frac": round(LUMA_FWD_BYTES_PER_PX * px / (k_alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}},
             "cpu_baseline": cpu,
+            # the pass-structured traffic model of the path (63 + c bytes per pixel each way, c = .comp bytes
+            # per pixel): what a stage-per-kernel pipeline would move; fusion keeps the real traffic below it
+            "pipeline_model": {"bytes_per_px_each_way": round(63 + bpp / 8, 3),
+                               "encode_gbps": round((63 + bpp / 8) * total_mp / t_enc / 1e3, 1),
+                               "decode_gbps": round((63 + bpp / 8) * total_mp / t_dec / 1e3, 1),
+                               "peak_gbps": HBM_PEAK_GBS * world},
+            "square_variant": square,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -26,6 +26,8 @@ static inline int khg_atomic_max_i(int* p, int v) { int o = *p; if (v > o) *p = 
 static inline void khg_lds_or(uint32_t* p, uint32_t v) { *p |= v; }
 static inline uint32_t khg_bswap32(uint32_t v) { return __builtin_bswap32(v); }
 static inline double khg_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+static inline unsigned long long khg_clock(void) { return 0; }
+static inline void khg_atomic_max64(unsigned long long* p, unsigned long long v) { if (v > *p) *p = v; }
 #else
 #include <hip/hip_runtime.h>
 #define KHG_DEV __device__ __forceinline__
@@ -41,6 +43,8 @@ __device__ __forceinline__ int khg_atomic_max_i(int* p, int v) { return atomicMa
 __device__ __forceinline__ void khg_lds_or(uint32_t* p, uint32_t v) { atomicOr(p, v); }  // result unused: ds_or_b32, no wait
 __device__ __forceinline__ uint32_t khg_bswap32(uint32_t v) { return __builtin_bswap32(v); }
 __device__ __forceinline__ double khg_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }  // explicit: not subject to -ffp-contract
+__device__ __forceinline__ unsigned long long khg_clock(void) { return (unsigned long long)wall_clock64(); }  // constant 100 MHz, chip-wide
+__device__ __forceinline__ void khg_atomic_max64(unsigned long long* p, unsigned long long v) { atomicMax(p, v); }
 #endif
 
 // ---------------------------------------------------------------- constants
@@ -64,6 +68,10 @@ struct KhgResult {
     int32_t k[3];          // table sizes
     int32_t pads[3];
     int32_t ok_to_pack;    // 1 when offsets are valid and the output fits
+    // measurement aid (khg_profile_luma_forward): device clock (100 MHz) at which the luma level-1 forward
+    // launch's first workgroup started, stored inverted so that zero-initialised memory and a max reduce give
+    // the minimum, and at which its last workgroup finished
+    unsigned long long prof_not_start, prof_end;
 };
 
 KHG_DEV void khg_set_status(int* status, int code)

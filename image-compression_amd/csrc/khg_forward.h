@@ -38,6 +38,7 @@ struct KhgFwdArgs {
     uint32_t* hist_cnt;        // [KHG_NBINS]
     uint32_t* hist_first;      // [KHG_NBINS]
     int* status;
+    KhgResult* prof;           // when set, the launch's first start / last end device clock go here
     int lvl;                   // preset 0..2
     int seg_rows;              // rows per workgroup segment (even)
     int nstrip;
@@ -255,6 +256,7 @@ KHG_DEV void khg_fwd_strip_body(const KhgFwdArgs& a, int bid, KhgFwdSmem<LEVEL>&
     KhgFwdRaw<SRC> raws[KHG_NSLOT(256)];
     KHG_FOR_THREADS(256)
     {
+        if (a.prof && tid == 0) khg_atomic_max64(&a.prof->prof_not_start, ~khg_clock());
         KhgLift z = {0, 0, 0, 0, 0};
         cs[KHG_SLOT] = z;
         KhgHot hz = {0, 0};
@@ -368,5 +370,6 @@ KHG_DEV void khg_fwd_strip_body(const KhgFwdArgs& a, int bid, KhgFwdSmem<LEVEL>&
                 khg_atomic_min(&a.hist_first[bin], sh.first[i]);
             }
         }
+        if (a.prof && tid == 0) khg_atomic_max64(&a.prof->prof_end, khg_clock());
     }
 }

@@ -150,7 +150,8 @@ struct khg_ctx {
     unsigned long long* sse; // [3] sums of squared errors
     // optional timing of the luma forward launch inside khg_encode_dev (khg_profile_luma_forward)
     int prof_on, prof_pending, prof_launches;
-    double prof_ms;
+    double prof_ms;      // event-to-event
+    double prof_dev_ms;  // device clock, first workgroup start to last workgroup end
     hipEvent_t prof_e0, prof_e1;
 };
 
@@ -274,6 +275,7 @@ static void khg_profile_collect(khg_ctx* c)
     float ms = 0;
     if (hipEventElapsedTime(&ms, c->prof_e0, c->prof_e1) == hipSuccess) {
         c->prof_ms += ms;
+        c->prof_dev_ms += (double)(c->h_res->prof_end - ~c->h_res->prof_not_start) / 1e5;  // 100 MHz ticks
         c->prof_launches++;
     }
 }
@@ -288,15 +290,17 @@ extern "C" int khg_profile_luma_forward(khg_ctx* c, int enable)
     }
     c->prof_on = enable != 0;
     c->prof_ms = 0;
+    c->prof_dev_ms = 0;
     c->prof_launches = 0;
     c->prof_pending = 0;
     return KHG_OK;
 }
 
-extern "C" int khg_profile_read(khg_ctx* c, double* total_ms, int* launches)
+extern "C" int khg_profile_read(khg_ctx* c, double* total_ms, double* total_device_ms, int* launches)
 {
-    if (!c || !total_ms || !launches) return KHG_ERR_ARG;
+    if (!c || !total_ms || !total_device_ms || !launches) return KHG_ERR_ARG;
     *total_ms = c->prof_ms;
+    *total_device_ms = c->prof_dev_ms;
     *launches = c->prof_launches;
     return KHG_OK;
 }
@@ -311,7 +315,10 @@ static int khg_enqueue_forward(khg_ctx* c, const uint8_t* r, const uint8_t* g, c
     KhgFwdGrid gr;
     KhgFwdArgs a;
     a = khg_fwd_args(ws, r, g, b, rows, cols, lvl, 0, 1, coef ? coef[0] : nullptr, &gr);
-    if (c->prof_on) KHG_HIP(hipEventRecord(c->prof_e0, st));
+    if (c->prof_on) {
+        KHG_HIP(hipEventRecord(c->prof_e0, st));
+        a.prof = ws.res;
+    }
     khg_launch_fwd<KHG_SRC_Y, 1>(a, gr, st);
     if (c->prof_on) {
         KHG_HIP(hipEventRecord(c->prof_e1, st));

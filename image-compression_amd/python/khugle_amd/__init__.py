@@ -9,3 +9,4 @@ from .bmp import read_bmp, write_bmp  # noqa: F401
 from .synth import synth_frame  # noqa: F401
 from .lib import KhgError, LIB_PATH, load  # noqa: F401
 from .codec import Codec, peek  # noqa: F401
+from .harness import load_bmp_and_compress, load_comp, save_comp  # noqa: F401

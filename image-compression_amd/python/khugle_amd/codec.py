@@ -114,11 +114,12 @@ class Codec:
         _check(self.L.khg_profile_luma_forward(self._ctx, 1 if enable else 0), "profile_luma_forward")
 
     def profile_read(self):
-        """(sum of milliseconds, launches) collected since profile_luma_forward()."""
+        """(event-to-event ms, device-clock ms, launches) summed since profile_luma_forward()."""
         ms = C.c_double(0)
+        dev = C.c_double(0)
         n = C.c_int(0)
-        _check(self.L.khg_profile_read(self._ctx, C.byref(ms), C.byref(n)), "profile_read")
-        return ms.value, n.value
+        _check(self.L.khg_profile_read(self._ctx, C.byref(ms), C.byref(dev), C.byref(n)), "profile_read")
+        return ms.value, dev.value, n.value
 
     def time_luma_forward_dev(self, rgb, lvl, reps=10):
         """Mean duration (ms) of the level-1 luma forward kernel, HIP events on the current stream."""

@@ -1,0 +1,99 @@
+"""Counterpart of the reference's two user-facing operations, CImageProcessing::LoadBMPAndCompress
+(Main.cpp:180-279) and CImageProcessing::LoadComp (Main.cpp:281-334), without the GUI: read a BMP, encode it,
+decode it again, and report the figures the application shows under "PSNR  SSIM  FILE SIZE".
+
+All codec and metric work runs on the GPU through the C ABI; this module only moves files and formats text.
+"""
+import os
+
+import numpy as np
+
+from .bmp import read_bmp, write_bmp
+from .codec import Codec, peek
+
+PRESETS = {"normal": 0, "high": 1, "extreme": 2}
+HEADER_STR = "PSNR         SSIM        FILE SIZE"  # Main.cpp:255
+
+
+class CompressReport:
+    """What LoadBMPAndCompress leaves behind: the file image, the round-tripped picture and the status line."""
+
+    def __init__(self, comp, decoded, psnr, ssim, original_file_size):
+        self.comp = comp
+        self.decoded = decoded
+        self.psnr = psnr
+        self.ssim = ssim
+        self.file_size = len(comp)
+        self.original_file_size = original_file_size
+
+    @property
+    def value_str(self):
+        # Main.cpp:257-260
+        return "%6.3f     %4.3f     %6.3fKB (%.3f %% of Original)" % (
+            self.psnr, self.ssim, self.file_size / 1024, self.file_size / self.original_file_size * 100)
+
+
+def _codec_for(h, w, codec):
+    if codec is not None:
+        return codec
+    return Codec(h, w)
+
+
+def load_bmp_and_compress(path, lvl, codec=None):
+    """Main.cpp:180-279.  lvl: 0 Normal, 1 High, 2 Extreme (or the names)."""
+    lvl = PRESETS.get(str(lvl).lower(), lvl)
+    rgb = read_bmp(path)
+    _, h, w = rgb.shape
+    c = _codec_for(h, w, codec)
+    t = c.torch
+    comp = c.encode(rgb, lvl)
+    decoded = c.decode(comp)  # the application decodes its own result to show it and to measure it
+    d_in = t.from_numpy(np.ascontiguousarray(rgb)).cuda(c.device)
+    d_out = t.from_numpy(decoded).cuda(c.device)
+    psnr = c.psnr_dev(d_in, d_out)          # GetPsnr on R, G, B (Main.cpp:241-248)
+    ssim = c.ssim_dev(d_in[0], d_out[0])    # ComputeSSIM on the R channel only (Main.cpp:250-253)
+    return CompressReport(comp, decoded, psnr, ssim, os.path.getsize(path))
+
+
+def save_comp(report, path):
+    """Menu "Save compressed image": WriteAll (Writer.h:43-69)."""
+    with open(path, "wb") as f:
+        f.write(report.comp)
+
+
+def load_comp(path, codec=None):
+    """Main.cpp:281-334: returns the (3, H, W) u8 picture and the status line ("%6.3fKB")."""
+    with open(path, "rb") as f:
+        comp = f.read()
+    hd = peek(comp)  # MeasureImageSize (Reader.h:97-110) plus validation
+    c = _codec_for(hd.h, hd.w, codec)
+    rgb = c.decode(comp)
+    return rgb, "%6.3fKB" % (len(comp) / 1024)
+
+
+def main(argv=None):
+    import argparse
+    ap = argparse.ArgumentParser(prog="python -m khugle_amd", description="bmp <-> comp on an MI355X")
+    sub = ap.add_subparsers(dest="cmd", required=True)
+    a = sub.add_parser("compress", help="BMP -> .comp (prints the application's PSNR / SSIM / size line)")
+    a.add_argument("bmp")
+    a.add_argument("comp")
+    a.add_argument("--preset", default="high", choices=sorted(PRESETS))
+    a.add_argument("--save-decoded", help="also write the round-tripped picture as a 24-bit BMP")
+    b = sub.add_parser("decompress", help=".comp -> BMP")
+    b.add_argument("comp")
+    b.add_argument("bmp")
+    args = ap.parse_args(argv)
+    if args.cmd == "compress":
+        rep = load_bmp_and_compress(args.bmp, args.preset)
+        save_comp(rep, args.comp)
+        if args.save_decoded:
+            write_bmp(args.save_decoded, rep.decoded)
+        print(HEADER_STR)
+        print(rep.value_str)
+    else:
+        rgb, line = load_comp(args.comp)
+        write_bmp(args.bmp, rgb)
+        print("FILE SIZE")
+        print(line)
+    return 0

@@ -107,10 +107,13 @@ int khg_time_luma_forward_dev(khg_ctx *ctx, const uint8_t *d_r, const uint8_t *d
                               int cols, int lvl, int reps, float *avg_ms, void *stream);
 
 /* Measurement aid: while enabled, khg_encode_dev brackets its luma level-1 forward launch with HIP events on
- * the caller's stream; khg_encode_result adds the elapsed time to a per-context tally that khg_profile_read
- * returns (sum of milliseconds, number of launches).  Enabling or disabling resets the tally. */
+ * the caller's stream, and the kernel notes the device clock at which its first workgroup starts and its last
+ * one ends; khg_encode_result adds both durations to per-context tallies that khg_profile_read returns
+ * (event-to-event milliseconds, which include the wait for the GPU when other streams are busy; device-clock
+ * milliseconds, which are the launch's execution span as a profiler reports it; number of launches).
+ * Enabling or disabling resets the tallies. */
 int khg_profile_luma_forward(khg_ctx *ctx, int enable);
-int khg_profile_read(khg_ctx *ctx, double *total_ms, int *launches);
+int khg_profile_read(khg_ctx *ctx, double *total_ms, double *total_device_ms, int *launches);
 
 /* ---- synthetic frames for benchmarks: deterministic integer arithmetic, identical to
  * khugle_amd.synth.synth_frame on the host.  Device planes. */

@@ -114,3 +114,28 @@ def test_malformed_files_are_rejected(codec):
     c3[35] = 7  # preset out of range
     with pytest.raises(KhgError):
         codec.decode(bytes(c3))
+
+
+def test_harness_reproduces_the_application_status_line(codec, tmp_path):
+    """LoadBMPAndCompress / Save / LoadComp counterpart on cat.bmp: the value line of Pictures/{Normal,High,Extreme}.png."""
+    from khugle_amd import harness
+    shots = json.load(open(os.path.join(GOLDEN, "screenshots.json")))
+    bmp = os.path.join(GOLDEN, "run", "cat.bmp")
+    for name, lvl in harness.PRESETS.items():
+        want = shots["presets"][str(lvl)]
+        rep = harness.load_bmp_and_compress(bmp, name, codec)
+        assert rep.value_str == "%s     %s     %sKB (%s %% of Original)" % (
+            want["psnr"], want["ssim"], want["size_kb"], want["percent"])
+        path = str(tmp_path / ("cat_%s.comp" % name))
+        harness.save_comp(rep, path)
+        rgb, line = harness.load_comp(path, codec)
+        assert np.array_equal(rgb, rep.decoded)
+        assert line == "%sKB" % want["size_kb"]
+    # the CLI writes the same file as the reference ships for cat.bmp at High
+    out = str(tmp_path / "cli.comp")
+    assert harness.main(["compress", bmp, out, "--preset", "high"]) == 0
+    assert open(out, "rb").read() == open(os.path.join(GOLDEN, "run", "cat_high.comp"), "rb").read()
+    back = str(tmp_path / "cli.bmp")
+    assert harness.main(["decompress", out, back]) == 0
+    from khugle_amd import read_bmp
+    assert np.array_equal(read_bmp(back), harness.load_comp(out, codec)[0])

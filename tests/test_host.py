@@ -6,7 +6,7 @@ import re
 import numpy as np
 import pytest
 
-from conftest import ROOT, RUN
+from conftest import GOLDEN, ROOT, RUN
 from khugle_amd import read_bmp, write_bmp
 from khugle_amd import lib as khg_lib
 
@@ -67,3 +67,17 @@ def test_product_sources_do_not_touch_the_oracle():
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "khugle_oracle" not in text and "oracle_py" not in text and "khgo_" not in text, f
                 assert "KHG_SIM 1" not in text, f
+
+
+def test_cli_parses_and_fails_loudly_without_a_gpu(tmp_path):
+    """The bmp <-> comp command line has no CPU path: on a machine without a HIP device it must raise."""
+    import torch
+    from khugle_amd import harness
+    with pytest.raises(SystemExit):
+        harness.main(["compress"])  # missing arguments
+    if not torch.cuda.is_available():
+        bmp = os.path.join(GOLDEN, "run", "cat.bmp")
+        assert os.path.exists(bmp)
+        with pytest.raises((khg_lib.KhgError, RuntimeError, OSError)):
+            harness.main(["compress", bmp, str(tmp_path / "x.comp")])
+        assert not os.path.exists(str(tmp_path / "x.comp"))
