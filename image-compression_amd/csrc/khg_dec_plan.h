@@ -44,8 +44,10 @@ static inline KhgFwdGrid khg_inv_grid(int ph, int pw)
 
 // Inverse-transform arguments of colour component comp at level 2 (into the LL buffer) or
 // level 1 (into the component's f64 plane).
+// Tiles: every rank decodes the whole symbol planes, so a tile only restricts the rows it reconstructs: its band at
+// level 1, and at level 2 that band of the LL quadrant widened by 4 rows (level 1 reads two row pairs beyond).
 static inline KhgInvArgs khg_inv_args(const KhgWorkspace& ws, const KhgDecWorkspace& dws, int rows, int cols,
-                                      int comp, int level, KhgFwdGrid* grid)
+                                      int comp, int level, KhgFwdGrid* grid, KhgTile tile = KhgTile{0, 1})
 {
     KhgInvArgs a;
     memset(&a, 0, sizeof a);
@@ -67,7 +69,16 @@ static inline KhgInvArgs khg_inv_args(const KhgWorkspace& ws, const KhgDecWorksp
     a.cr = dws.plane[2];
     a.hdr = dws.hdr;
     for (int lvl = 0; lvl < 3; ++lvl) khg_make_quant(rows, cols, lvl, comp != 0, &a.q[lvl]);
-    *grid = khg_inv_grid(a.ph, a.pw);
+    const int R0 = khg_tile_row0(prow, tile), R1 = khg_tile_row1(prow, tile);
+    if (level == 1) {
+        a.row_begin = R0;
+        a.row_end = R1;
+    } else {
+        a.row_begin = R0 / 2 - 4 < 0 ? 0 : R0 / 2 - 4;
+        a.row_end = R1 / 2 + 4 > a.ph ? a.ph : R1 / 2 + 4;
+    }
+    a.out_row0 = khg_tile_row0(rows, tile);
+    *grid = khg_inv_grid(a.row_end - a.row_begin, a.pw);
     a.seg_rows = grid->seg_rows;
     a.nstrip = grid->nstrip;
     return a;

@@ -24,8 +24,9 @@ enum {
 };
 
 struct KhgFwdArgs {
-    const uint8_t *r, *g, *b;  // full-resolution RGB planes
+    const uint8_t *r, *g, *b;  // full-resolution RGB planes, or a band of their rows
     int img_w;                 // their row pitch (image columns)
+    int in_row0;               // image row held by the first row of r/g/b (0 for a whole image)
     const double* src;         // KHG_SRC_PLANE: f64 source plane
     int src_pitch;
     int ph, pw;                // rows, cols of this transform
@@ -40,6 +41,9 @@ struct KhgFwdArgs {
     int* status;
     KhgResult* prof;           // when set, the launch's first start / last end device clock go here
     int lvl;                   // preset 0..2
+    int row_begin, row_end;    // plane rows this launch transforms (even; the whole plane, or one tile's band)
+    int emit_k0, emit_k1;      // row pairs whose detail symbols are stored and counted (a tile recomputes its
+                               // neighbours' edge rows for the LL quadrant only)
     int seg_rows;              // rows per workgroup segment (even)
     int nstrip;
     KhgQuant q;
@@ -124,7 +128,7 @@ KHG_DEV void khg_fwd_fetch(const KhgFwdArgs& a, KhgFwdRaw<SRC>& raw, int gy, int
             __builtin_memcpy(&raw.w[4 * k + 2], &v1, 8);
         }
     } else if (SRC == KHG_SRC_Y) {
-        const size_t rowoff = (size_t)gy * a.img_w;
+        const size_t rowoff = (size_t)(gy - a.in_row0) * a.img_w;
         KHG_UNROLL
         for (int k = 0; k < 6; ++k) {
             int gx = gx0 + 4 * k;
@@ -145,7 +149,7 @@ KHG_DEV void khg_fwd_fetch(const KhgFwdArgs& a, KhgFwdRaw<SRC>& raw, int gy, int
         }
     } else {
         // chroma site (gy, gx) reads the pixel at (2gy, 2gx): Colorspace.h:16-21
-        const size_t rowoff = (size_t)(2 * gy) * a.img_w;
+        const size_t rowoff = (size_t)(2 * gy - a.in_row0) * a.img_w;
         KHG_UNROLL
         for (int k = 0; k < 6; ++k) {
             int gx = gx0 + 4 * k;
@@ -244,8 +248,8 @@ KHG_DEV void khg_fwd_strip_body(const KhgFwdArgs& a, int bid, KhgFwdSmem<LEVEL>&
 {
     const int strip = bid % a.nstrip, seg = bid / a.nstrip;
     const int x0 = strip * KHG_STRIP;
-    const int r0 = seg * a.seg_rows;
-    const int r1 = (r0 + a.seg_rows < a.ph) ? r0 + a.seg_rows : a.ph;
+    const int r0 = a.row_begin + seg * a.seg_rows;
+    const int r1 = (r0 + a.seg_rows < a.row_end) ? r0 + a.seg_rows : a.row_end;
     const int rin0 = r0 - 4;
     const int k0 = r0 / 2, k1 = r1 / 2;
     const int nb = (r1 - r0 + 8 + KHG_BATCH - 1) / KHG_BATCH;
@@ -326,15 +330,16 @@ KHG_DEV void khg_fwd_strip_body(const KhgFwdArgs& a, int bid, KhgFwdSmem<LEVEL>&
                         a.coef[(size_t)k * a.coef_pitch + xo] = lo;
                         a.coef[(size_t)(hh + k) * a.coef_pitch + xo] = hi;
                     }
+                    const bool emit = k >= a.emit_k0 && k < a.emit_k1;
                     if (LEVEL == 1) {
                         if (half == 0) {
                             a.ll[(size_t)k * a.ll_pitch + xq] = lo;
-                            khg_quant_store(a, sh, hot, hi, rd[1 * KHG_RD_N], 5, 1, hh + k, xo);
-                        } else {
+                            if (emit) khg_quant_store(a, sh, hot, hi, rd[1 * KHG_RD_N], 5, 1, hh + k, xo);
+                        } else if (emit) {
                             khg_quant_store(a, sh, hot, lo, rd[0 * KHG_RD_N], 4, 0, k, xo);
                             khg_quant_store(a, sh, hot, hi, rd[2 * KHG_RD_N], 6, 1, hh + k, xo);
                         }
-                    } else {
+                    } else if (emit) {
                         if (half == 0) {
                             khg_quant_store(a, sh, hot, lo, rd[0 * KHG_RD_N], 0, 0, k, xo);
                             khg_quant_store(a, sh, hot, hi, rd[2 * KHG_RD_N], 2, 1, hh + k, xo);

@@ -28,8 +28,8 @@ extern "C" int khg_peek(const uint8_t* comp, size_t len, khg_header* hdr)
     return KHG_OK;
 }
 
-extern "C" int khg_decode_dev(khg_ctx* c, const uint8_t* d_comp, size_t len, int rows, int cols, uint8_t* d_r,
-                              uint8_t* d_g, uint8_t* d_b, void* stream)
+static int khg_decode_enqueue(khg_ctx* c, const uint8_t* d_comp, size_t len, int rows, int cols, uint8_t* d_r,
+                              uint8_t* d_g, uint8_t* d_b, void* stream, KhgTile tile)
 {
     int rc = khg_check_image(c, rows, cols);
     if (rc) return rc;
@@ -48,11 +48,11 @@ extern "C" int khg_decode_dev(khg_ctx* c, const uint8_t* d_comp, size_t len, int
     hipLaunchKernelGGL(khg_dec_write_kernel, dim3(d.nblocks), dim3(256), 0, st, d);
     KhgFwdGrid gr;
     for (int p = 0; p < 3; ++p) {  // Decompress.h:274-276
-        KhgInvArgs a = khg_inv_args(c->ws, c->dws, rows, cols, p, 2, &gr);
+        KhgInvArgs a = khg_inv_args(c->ws, c->dws, rows, cols, p, 2, &gr, tile);
         hipLaunchKernelGGL((khg_inv_kernel<2, false>), dim3(gr.nstrip * gr.nseg), dim3(256), 0, st, a);
     }
     for (int p = 2; p >= 0; --p) {  // Decompress.h:278-280; luma last: it also does Decompress.h:282 + Main.cpp:307-315
-        KhgInvArgs a = khg_inv_args(c->ws, c->dws, rows, cols, p, 1, &gr);
+        KhgInvArgs a = khg_inv_args(c->ws, c->dws, rows, cols, p, 1, &gr, tile);
         if (p == 0) {
             a.r = d_r; a.g = d_g; a.b = d_b;
             hipLaunchKernelGGL((khg_inv_kernel<1, true>), dim3(gr.nstrip * gr.nseg), dim3(256), 0, st, a);
@@ -66,6 +66,12 @@ extern "C" int khg_decode_dev(khg_ctx* c, const uint8_t* d_comp, size_t len, int
     c->last_stream = st;
     c->pending = 2;
     return KHG_OK;
+}
+
+extern "C" int khg_decode_dev(khg_ctx* c, const uint8_t* d_comp, size_t len, int rows, int cols, uint8_t* d_r,
+                              uint8_t* d_g, uint8_t* d_b, void* stream)
+{
+    return khg_decode_enqueue(c, d_comp, len, rows, cols, d_r, d_g, d_b, stream, KhgTile{0, 1});
 }
 
 extern "C" int khg_last_status(khg_ctx* c)

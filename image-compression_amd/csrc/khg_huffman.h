@@ -290,6 +290,15 @@ struct KhgEncArgs {
     const int16_t* sym[3];     // quantised planes, raster order
     uint32_t n[3];             // symbols per plane
     uint32_t chunk0[3];        // first chunk index of each plane
+    // Row-tiled images (nranks > 1): a rank computed the symbols of its row pairs at each level, which in the
+    // Mallat layout are, per plane of prow x pcol symbols (hh = prow/2, hw = pcol/2),
+    //   left half of row r < hh   (level 2)           : rank of r within [0, hh/2) or [hh/2, hh), split evenly
+    //   right half of row r < hh  (level 1, band 4)   : rank of row pair k = r
+    //   whole row r >= hh         (level 1, bands 5|6): rank of row pair k = r - hh
+    // so the raster is cut into these runs, each run into chunks of its own, and a rank lens/packs its runs only.
+    int rank, nranks;
+    int prow[3], pcol[3];
+    int write_meta;            // this rank writes the header and the tables
     uint32_t nchunks;          // total
     const uint64_t* codetab;   // [3][KHG_NBINS]
     uint32_t* chunk_bits;      // [nchunks]
@@ -308,6 +317,50 @@ KHG_DEV int khg_chunk_plane(const KhgEncArgs& a, uint32_t chunk)
     return chunk >= a.chunk0[2] ? 2 : chunk >= a.chunk0[1] ? 1 : 0;
 }
 
+// Chunks of one run of `len` symbols.
+KHG_DEV uint32_t khg_run_chunks(uint32_t len) { return (len + KHG_CHUNK - 1) / KHG_CHUNK; }
+
+// A chunk of the symbol stream: plane, raster range [sym0, sym0 + nsym), and whether this rank owns it.
+struct KhgChunk {
+    int plane;
+    uint32_t sym0, nsym;
+    bool mine;
+};
+
+KHG_DEV KhgChunk khg_chunk_info(const KhgEncArgs& a, uint32_t chunk)
+{
+    KhgChunk c;
+    c.plane = khg_chunk_plane(a, chunk);
+    const uint32_t lc = chunk - a.chunk0[c.plane];
+    if (a.nranks <= 1) {  // the plane's raster in chunks of KHG_CHUNK
+        c.sym0 = lc * KHG_CHUNK;
+        c.nsym = a.n[c.plane] - c.sym0 < KHG_CHUNK ? a.n[c.plane] - c.sym0 : KHG_CHUNK;
+        c.mine = true;
+        return c;
+    }
+    const uint32_t prow = (uint32_t)a.prow[c.plane], pcol = (uint32_t)a.pcol[c.plane], hh = prow / 2, hw = pcol / 2;
+    const uint32_t ch = khg_run_chunks(hw), cw = khg_run_chunks(pcol);
+    uint32_t run_sym0, run_len, j, owner;
+    if (lc < hh * 2 * ch) {
+        const uint32_t r = lc / (2 * ch), rest = lc - r * 2 * ch, right = rest >= ch;
+        j = right ? rest - ch : rest;
+        run_sym0 = r * pcol + (right ? hw : 0);
+        run_len = hw;
+        if (right) owner = r / (hh / (uint32_t)a.nranks);
+        else owner = (r < hh / 2 ? r : r - hh / 2) / (hh / 2 / (uint32_t)a.nranks);
+    } else {
+        const uint32_t l2 = lc - hh * 2 * ch, k = l2 / cw;
+        j = l2 - k * cw;
+        run_sym0 = (hh + k) * pcol;
+        run_len = pcol;
+        owner = k / (hh / (uint32_t)a.nranks);
+    }
+    c.sym0 = run_sym0 + j * KHG_CHUNK;
+    c.nsym = run_len - j * KHG_CHUNK < KHG_CHUNK ? run_len - j * KHG_CHUNK : KHG_CHUNK;
+    c.mine = owner == (uint32_t)a.rank;
+    return c;
+}
+
 struct KhgLensSmem {
     uint32_t part[256];
 };
@@ -315,16 +368,17 @@ struct KhgLensSmem {
 // One chunk per workgroup, 8 symbols per thread.
 KHG_DEV void khg_lens_body(const KhgEncArgs& a, uint32_t chunk, KhgLensSmem& sh)
 {
-    const int p = khg_chunk_plane(a, chunk);
+    const KhgChunk ck = khg_chunk_info(a, chunk);
+    if (!ck.mine) return;  // another rank's symbols: its entry of chunk_bits stays zero here
+    const int p = ck.plane;
     const uint64_t* ctab = a.codetab + (size_t)p * KHG_NBINS;
-    const uint32_t base = (chunk - a.chunk0[p]) * KHG_CHUNK;
+    const uint32_t base = ck.sym0, end = ck.sym0 + ck.nsym;
     KHG_FOR_THREADS(256)
     {
         uint32_t s0 = base + (uint32_t)tid * 8, bits = 0;
-        if (s0 < a.n[p]) {
-            const int16_t* q = a.sym[p] + s0;
-            for (int i = 0; i < 8; ++i) bits += (uint32_t)(ctab[q[i] + KHG_SYM_BIAS] >> 56);
-        }
+        const int16_t* q = a.sym[p] + s0;
+        for (int i = 0; i < 8; ++i)
+            if (s0 + i < end) bits += (uint32_t)(ctab[q[i] + KHG_SYM_BIAS] >> 56);
         sh.part[tid] = bits;
     }
     KHG_BARRIER();
@@ -411,7 +465,7 @@ KHG_DEV void khg_scan_body(const KhgEncArgs& a, KhgScanSmem& sh)
             sh.table_off = table_off;
             sh.ok = ok;
             res->ok_to_pack = ok;
-            if (ok) {
+            if (ok && a.write_meta) {
                 // Writer.h:9-23.  Offsets 24/28: rows, cols (equal for the square images the
                 // reference supports; it passes (img_height, img_width) into Type.h:18's (w, h) slots).
                 uint8_t* o = a.out;
@@ -458,7 +512,7 @@ KHG_DEV void khg_scan_body(const KhgEncArgs& a, KhgScanSmem& sh)
     KHG_BARRIER();
     KHG_FOR_THREADS(1024)
     {
-        if (sh.ok) {
+        if (sh.ok && a.write_meta) {
             // Writer.h:34-41: (int32 count, int32 symbol) per entry, Y then Cb then Cr
             uint8_t* t = a.out + sh.table_off;
             uint32_t kk[3] = {(uint32_t)a.tab_k[0], (uint32_t)a.tab_k[1], (uint32_t)a.tab_k[2]};
@@ -487,9 +541,11 @@ struct KhgPackSmem {
 KHG_DEV void khg_pack_body(const KhgEncArgs& a, uint32_t chunk, KhgPackSmem& sh)
 {
     if (!a.res->ok_to_pack) return;
-    const int p = khg_chunk_plane(a, chunk);
+    const KhgChunk ck = khg_chunk_info(a, chunk);
+    if (!ck.mine) return;
+    const int p = ck.plane;
     const uint64_t* ctab = a.codetab + (size_t)p * KHG_NBINS;
-    const uint32_t base = (chunk - a.chunk0[p]) * KHG_CHUNK;
+    const uint32_t base = ck.sym0, end = ck.sym0 + ck.nsym;
     const uint32_t bits = a.chunk_bits[chunk];
     if (bits == 0) return;
     const uint64_t off = a.chunk_off[chunk];
@@ -503,7 +559,7 @@ KHG_DEV void khg_pack_body(const KhgEncArgs& a, uint32_t chunk, KhgPackSmem& sh)
         uint32_t s0 = base + (uint32_t)tid * 8, tb = 0;
         for (int i = 0; i < 8; ++i) {
             uint64_t c = 0;
-            if (s0 < a.n[p]) c = ctab[a.sym[p][s0 + i] + KHG_SYM_BIAS];
+            if (s0 + i < end) c = ctab[a.sym[p][s0 + i] + KHG_SYM_BIAS];
             code[KHG_SLOT][i] = c;
             tb += (uint32_t)(c >> 56);
         }

@@ -33,6 +33,8 @@ struct KhgInvArgs {
     double* dst;          // natural-order output, ph x pw
     int dst_pitch;
     const KhgDecHeader* hdr;  // supplies the preset (lvl) and the go/no-go flag
+    int row_begin, row_end;  // output rows this launch produces (even; the whole plane, or one tile's band)
+    int out_row0;         // RGB variant: image row held by the first row of r/g/b (0 for a whole image)
     int seg_rows;         // output rows per workgroup segment (even)
     int nstrip;
     KhgQuant q[3];        // quantiser constants of this plane type for presets 0..2
@@ -138,8 +140,8 @@ KHG_DEV void khg_inv_strip_body(const KhgInvArgs& a, int bid, KhgInvSmem& sh)
 {
     const int strip = bid % a.nstrip, seg = bid / a.nstrip;
     const int x0 = strip * KHG_ISTRIP;
-    const int r0 = seg * a.seg_rows;
-    const int r1 = (r0 + a.seg_rows < a.ph) ? r0 + a.seg_rows : a.ph;
+    const int r0 = a.row_begin + seg * a.seg_rows;
+    const int r1 = (r0 + a.seg_rows < a.row_end) ? r0 + a.seg_rows : a.row_end;
     const int k0 = r0 / 2, k1 = r1 / 2;
     const int nb = (k1 - k0 + 4 + KHG_IBATCH - 1) / KHG_IBATCH;
     const int hh = a.ph / 2, hw = a.pw / 2;
@@ -254,7 +256,7 @@ KHG_DEV void khg_inv_strip_body(const KhgInvArgs& a, int bid, KhgInvSmem& sh)
                         khg_rgb_pair(yv[2 * c], yv[2 * c + 1], cbv[c], crv[c], rgb);
                         for (int ch = 0; ch < 3; ++ch) pk[ch][c >> 2] |= (uint64_t)rgb[ch] << (16 * (c & 3));
                     }
-                    const size_t p = (size_t)gy * a.pw + gx0;
+                    const size_t p = (size_t)(gy - a.out_row0) * a.pw + gx0;
                     *(uint64_t*)(a.r + p) = pk[0][0];
                     *(uint64_t*)(a.g + p) = pk[1][0];
                     *(uint64_t*)(a.b + p) = pk[2][0];

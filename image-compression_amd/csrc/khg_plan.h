@@ -65,6 +65,15 @@ struct KhgWorkspace {
 
 static inline uint32_t khg_nchunks(uint32_t n) { return (n + KHG_CHUNK - 1) / KHG_CHUNK; }
 
+// Chunks of one plane of prow x pcol symbols: KHG_CHUNK-symbol pieces of the raster, or, for a row-tiled image,
+// of the runs of khg_chunk_info.
+static inline uint32_t khg_plane_chunks(int prow, int pcol, int nranks)
+{
+    if (nranks <= 1) return khg_nchunks((uint32_t)((size_t)prow * pcol));
+    const uint32_t hh = (uint32_t)prow / 2;
+    return hh * 2 * khg_nchunks((uint32_t)pcol / 2) + hh * khg_nchunks((uint32_t)pcol);
+}
+
 // Byte sizes of the workspace arrays for images up to rows x cols.
 struct KhgWorkspaceSizes {
     size_t ll[3], sym[3], hist, tab, codetab, big_scratch, tree, chunk_bits, chunk_off;
@@ -81,7 +90,10 @@ static inline void khg_workspace_sizes(int rows, int cols, KhgWorkspaceSizes* s)
     s->codetab = 3 * (size_t)KHG_NBINS * sizeof(uint64_t);
     s->big_scratch = 3 * (size_t)10 * KHG_NBINS * sizeof(uint32_t);
     s->tree = 3 * (size_t)2 * KHG_NBINS * sizeof(int32_t);
+    // plain chunking, or the row-run chunking of tiled images, whichever has more chunks
     size_t nch = khg_nchunks((uint32_t)ny) + 2 * khg_nchunks((uint32_t)nc);
+    size_t nch_tiled = khg_plane_chunks(rows, cols, 2) + 2 * (size_t)khg_plane_chunks(rows / 2, cols / 2, 2);
+    if (nch_tiled > nch) nch = nch_tiled;
     s->chunk_bits = nch * sizeof(uint32_t);
     s->chunk_off = nch * sizeof(uint64_t);
 }
@@ -127,11 +139,40 @@ static inline KhgFwdGrid khg_fwd_grid(int ph, int pw, int level)
     return khg_strip_grid(ph, (pw + KHG_STRIP - 1) / KHG_STRIP, level == 1 ? 1024 : 768, 8, KHG_MAX_SEG_ROWS);
 }
 
+// One tile of a row-tiled image: rank t of n owns image rows [rows*t/n, rows*(t+1)/n), rows/n a multiple of 8
+// so luma and chroma bands line up at both levels.  {0, 1} is the whole image.
+struct KhgTile {
+    int rank, nranks;
+};
+enum { KHG_TILE_HALO = 24 };  // image rows a tile needs beyond its own on each side (see khg_fwd_args)
+
+static inline int khg_tile_ok(int rows, KhgTile t)
+{
+    return t.nranks >= 1 && t.nranks <= 8 && t.rank >= 0 && t.rank < t.nranks && rows % (8 * t.nranks) == 0;
+}
+static inline int khg_tile_row0(int rows, KhgTile t) { return rows / t.nranks * t.rank; }
+static inline int khg_tile_row1(int rows, KhgTile t) { return rows / t.nranks * (t.rank + 1); }
+// first image row a tile's input buffer must hold, and one past the last
+static inline int khg_tile_in_row0(int rows, KhgTile t)
+{
+    int r = khg_tile_row0(rows, t) - KHG_TILE_HALO;
+    return r < 0 ? 0 : r;
+}
+static inline int khg_tile_in_row1(int rows, KhgTile t)
+{
+    int r = khg_tile_row1(rows, t) + KHG_TILE_HALO;
+    return r > rows ? rows : r;
+}
+
 // Forward-transform arguments of colour component comp (0 Y, 1 Cb, 2 Cr) at level 1 or 2.
 // coef (optional) is the component's full f64 coefficient plane.
+// Tiles: level 2 of a tile's band [R0/2, R1/2) of the LL quadrant reads LL rows R0/2-4 .. R1/2+4, so level 1 is
+// run over plane rows R0-8 .. R1+8 (symbols emitted for R0 .. R1 only), which reads plane rows R0-12 .. R1+12:
+// 12 luma rows, or 12 chroma rows = 24 image rows, beyond the tile on each side.  r, g, b point at image row
+// khg_tile_in_row0().  Every output is a fixed expression of the inputs, so the recomputed rows are bit-exact.
 static inline KhgFwdArgs khg_fwd_args(const KhgWorkspace& ws, const uint8_t* r, const uint8_t* g, const uint8_t* b,
                                       int rows, int cols, int lvl, int comp, int level, double* coef,
-                                      KhgFwdGrid* grid)
+                                      KhgFwdGrid* grid, KhgTile tile = KhgTile{0, 1})
 {
     KhgFwdArgs a;
     memset(&a, 0, sizeof a);
@@ -156,7 +197,20 @@ static inline KhgFwdArgs khg_fwd_args(const KhgWorkspace& ws, const uint8_t* r, 
     a.status = &ws.res->status;
     a.lvl = lvl;
     khg_make_quant(rows, cols, lvl, comp != 0, &a.q);
-    *grid = khg_fwd_grid(a.ph, a.pw, level);
+    a.in_row0 = khg_tile_in_row0(rows, tile);
+    const int R0 = khg_tile_row0(prow, tile), R1 = khg_tile_row1(prow, tile);  // the tile's band of this component
+    if (level == 1) {
+        a.row_begin = R0 - 8 < 0 ? 0 : R0 - 8;
+        a.row_end = R1 + 8 > prow ? prow : R1 + 8;
+        a.emit_k0 = R0 / 2;
+        a.emit_k1 = R1 / 2;
+    } else {
+        a.row_begin = R0 / 2;
+        a.row_end = R1 / 2;
+        a.emit_k0 = a.row_begin / 2;
+        a.emit_k1 = a.row_end / 2;
+    }
+    *grid = khg_fwd_grid(a.row_end - a.row_begin, a.pw, level);
     a.seg_rows = grid->seg_rows;
     a.nstrip = grid->nstrip;
     return a;
@@ -173,16 +227,23 @@ static inline KhgTableArgs khg_table_args(const KhgWorkspace& ws)
     return t;
 }
 
-static inline KhgEncArgs khg_enc_args(const KhgWorkspace& ws, int rows, int cols, int lvl, uint8_t* out, size_t cap)
+static inline KhgEncArgs khg_enc_args(const KhgWorkspace& ws, int rows, int cols, int lvl, uint8_t* out, size_t cap,
+                                      KhgTile tile = KhgTile{0, 1})
 {
     KhgEncArgs e;
     memset(&e, 0, sizeof e);
-    uint32_t ny = (uint32_t)((size_t)rows * cols), nc = ny / 4;
-    e.n[0] = ny; e.n[1] = nc; e.n[2] = nc;
-    e.chunk0[0] = 0;
-    e.chunk0[1] = khg_nchunks(ny);
-    e.chunk0[2] = e.chunk0[1] + khg_nchunks(nc);
-    e.nchunks = e.chunk0[2] + khg_nchunks(nc);
+    uint32_t chunk = 0;
+    for (int p = 0; p < 3; ++p) {
+        e.prow[p] = p ? rows / 2 : rows;
+        e.pcol[p] = p ? cols / 2 : cols;
+        e.n[p] = (uint32_t)((size_t)e.prow[p] * e.pcol[p]);
+        e.chunk0[p] = chunk;
+        chunk += khg_plane_chunks(e.prow[p], e.pcol[p], tile.nranks);
+    }
+    e.nchunks = chunk;
+    e.rank = tile.rank;
+    e.nranks = tile.nranks;
+    e.write_meta = tile.rank == 0;
     for (int p = 0; p < 3; ++p) e.sym[p] = ws.sym[p];
     e.codetab = ws.codetab;
     e.chunk_bits = ws.chunk_bits; e.chunk_off = ws.chunk_off;

@@ -153,6 +153,9 @@ struct khg_ctx {
     double prof_ms;      // event-to-event
     double prof_dev_ms;  // device clock, first workgroup start to last workgroup end
     hipEvent_t prof_e0, prof_e1;
+    // tiled encode in progress (khg_tile_*)
+    KhgTile tile;
+    int tile_rows, tile_cols, tile_lvl;
 };
 
 static size_t khg_align(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -306,7 +309,7 @@ extern "C" int khg_profile_read(khg_ctx* c, double* total_ms, double* total_devi
 }
 
 static int khg_enqueue_forward(khg_ctx* c, const uint8_t* r, const uint8_t* g, const uint8_t* b, int rows, int cols,
-                               int lvl, double* const coef[3], hipStream_t st)
+                               int lvl, double* const coef[3], hipStream_t st, KhgTile tile = KhgTile{0, 1})
 {
     KhgWorkspace& ws = c->ws;
     KHG_HIP(hipMemsetAsync(ws.hist_cnt, 0, 3 * KHG_NBINS * sizeof(uint32_t), st));
@@ -314,7 +317,7 @@ static int khg_enqueue_forward(khg_ctx* c, const uint8_t* r, const uint8_t* g, c
     KHG_HIP(hipMemsetAsync(ws.res, 0, sizeof(KhgResult), st));
     KhgFwdGrid gr;
     KhgFwdArgs a;
-    a = khg_fwd_args(ws, r, g, b, rows, cols, lvl, 0, 1, coef ? coef[0] : nullptr, &gr);
+    a = khg_fwd_args(ws, r, g, b, rows, cols, lvl, 0, 1, coef ? coef[0] : nullptr, &gr, tile);
     if (c->prof_on) {
         KHG_HIP(hipEventRecord(c->prof_e0, st));
         a.prof = ws.res;
@@ -324,12 +327,12 @@ static int khg_enqueue_forward(khg_ctx* c, const uint8_t* r, const uint8_t* g, c
         KHG_HIP(hipEventRecord(c->prof_e1, st));
         c->prof_pending = 1;
     }
-    a = khg_fwd_args(ws, r, g, b, rows, cols, lvl, 1, 1, coef ? coef[1] : nullptr, &gr);
+    a = khg_fwd_args(ws, r, g, b, rows, cols, lvl, 1, 1, coef ? coef[1] : nullptr, &gr, tile);
     khg_launch_fwd<KHG_SRC_CB, 1>(a, gr, st);
-    a = khg_fwd_args(ws, r, g, b, rows, cols, lvl, 2, 1, coef ? coef[2] : nullptr, &gr);
+    a = khg_fwd_args(ws, r, g, b, rows, cols, lvl, 2, 1, coef ? coef[2] : nullptr, &gr, tile);
     khg_launch_fwd<KHG_SRC_CR, 1>(a, gr, st);
     for (int p = 0; p < 3; ++p) {
-        a = khg_fwd_args(ws, r, g, b, rows, cols, lvl, p, 2, coef ? coef[p] : nullptr, &gr);
+        a = khg_fwd_args(ws, r, g, b, rows, cols, lvl, p, 2, coef ? coef[p] : nullptr, &gr, tile);
         khg_launch_fwd<KHG_SRC_PLANE, 2>(a, gr, st);
     }
     KHG_HIP(hipGetLastError());
@@ -493,3 +496,4 @@ extern "C" int khg_synth_dev(uint8_t* d_r, uint8_t* d_g, uint8_t* d_b, int rows,
 }
 
 #include "khg_host_decode.inl"
+#include "khg_host_tile.inl"

@@ -75,6 +75,10 @@ class Codec:
     def last_status(self):
         return self.L.khg_last_status(self._ctx)
 
+    def last_status_after_decode(self):
+        """Waits for the context's last job and returns its device-side status (0 = ok)."""
+        return self.L.khg_last_status(self._ctx)
+
     def ssim_dev(self, a, b):
         """SSIM of two (H, W) uint8 cuda planes (the reference passes the R channel)."""
         h, w = a.shape

@@ -45,6 +45,16 @@ SYMBOLS = [
     ("khg_decode", C.c_int, [_P, _P, C.c_size_t, _P, _P, _P]),
     ("khg_decode_dev", C.c_int, [_P, _P, C.c_size_t, C.c_int, C.c_int, _P, _P, _P, _P]),
     ("khg_last_status", C.c_int, [_P]),
+    ("khg_tile_input_rows", C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    ("khg_tile_chunk_count", C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    ("khg_tile_forward_dev", C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    ("khg_tile_hist_get", C.c_int, [_P, _P, _P, _P]),
+    ("khg_tile_hist_set", C.c_int, [_P, _P, _P, _P]),
+    ("khg_tile_lens_dev", C.c_int, [_P, _P]),
+    ("khg_tile_bits_get", C.c_int, [_P, _P, _P]),
+    ("khg_tile_bits_set", C.c_int, [_P, _P, _P]),
+    ("khg_tile_pack_dev", C.c_int, [_P, _P, C.c_size_t, _P]),
+    ("khg_tile_decode_dev", C.c_int, [_P, _P, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P]),
     ("khg_profile_luma_forward", C.c_int, [_P, C.c_int]),
     ("khg_profile_read", C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     ("khg_ssim_dev", C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.POINTER(C.c_double), _P]),

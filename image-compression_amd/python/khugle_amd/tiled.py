@@ -1,0 +1,164 @@
+"""One image tiled by rows over several GPUs (one process per GPU): the host layer that runs the collectives
+between the per-GPU steps of the C ABI (khg_tile_* in include/khugle_hip.h).
+
+Rank t of n owns image rows [rows*t/n, rows*(t+1)/n).  Data movement between ranks:
+  * exchange_halos : 24 rows to each neighbour, point to point (the DWT halos)
+  * histogram      : all-reduce SUM of the symbol counts, all-reduce MIN of the first raster indices
+                     -> every rank builds the same table, tree and codes
+  * chunk bits     : all-reduce SUM -> every rank knows the bit offset of every chunk
+  * file bytes     : reduce SUM of the ranks' disjoint shares to the rank that keeps the file
+On GPUs the process group is RCCL (backend "nccl"); the CPU tests run the same code over gloo with the kernel
+simulator behind the same backend interface.
+"""
+import ctypes as C
+
+import torch
+import torch.distributed as dist
+
+from . import lib as _lib
+from .codec import _check, _ptr, _stream
+
+HALO = 24          # image rows a tile needs beyond its own on each side
+NBINS = 16384
+_ABSENT = 0x7FFFFFFF
+
+
+def tile_rows(rows, rank, world):
+    """[first, last) image rows owned by `rank`."""
+    if rows % (8 * world) != 0:
+        raise ValueError("rows must be a multiple of 8 * ranks")
+    return rows // world * rank, rows // world * (rank + 1)
+
+
+def input_rows(rows, rank, world):
+    """[first, last) image rows a rank's input strip must hold: its tile plus the halo, clipped to the image."""
+    r0, r1 = tile_rows(rows, rank, world)
+    return max(0, r0 - HALO), min(rows, r1 + HALO)
+
+
+def exchange_halos(own, rank, world, group=None):
+    """own: (3, R, W) uint8 tensor with the rank's own rows.  Returns the strip with the neighbours' edge rows
+    attached (top rank and bottom rank have none on the outer side)."""
+    _, R, W = own.shape
+    if R < HALO:
+        raise ValueError("tiles must be at least %d rows high" % HALO)
+    up = torch.empty((3, HALO, W), dtype=own.dtype, device=own.device) if rank > 0 else None
+    down = torch.empty((3, HALO, W), dtype=own.dtype, device=own.device) if rank < world - 1 else None
+    ops = []
+    if rank > 0:
+        ops.append(dist.P2POp(dist.isend, own[:, :HALO].contiguous(), rank - 1, group))
+        ops.append(dist.P2POp(dist.irecv, up, rank - 1, group))
+    if rank < world - 1:
+        ops.append(dist.P2POp(dist.isend, own[:, R - HALO:].contiguous(), rank + 1, group))
+        ops.append(dist.P2POp(dist.irecv, down, rank + 1, group))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    parts = [p for p in (up, own, down) if p is not None]
+    return torch.cat(parts, dim=1).contiguous()
+
+
+class HipTileBackend:
+    """The per-GPU steps on a khugle_amd.Codec (device tensors, torch's current stream)."""
+
+    def __init__(self, codec):
+        self.c = codec
+        self.L = codec.L
+        self.dev = torch.device("cuda", codec.device)
+
+    def comp_bound(self, rows, cols):
+        return int(self.L.khg_comp_bound(rows, cols))
+
+    def forward(self, strip, rows, cols, lvl, rank, world):
+        assert strip.is_cuda and strip.dtype == torch.uint8 and strip.is_contiguous()
+        i0, i1 = input_rows(rows, rank, world)
+        assert tuple(strip.shape) == (3, i1 - i0, cols), "strip must hold image rows %d..%d" % (i0, i1)
+        self.shape = (rows, cols, world)
+        _check(self.L.khg_tile_forward_dev(self.c._ctx, _ptr(strip[0]), _ptr(strip[1]), _ptr(strip[2]), rows, cols, lvl,
+                                           rank, world, _stream()), "tile_forward")
+
+    def hist_get(self):
+        cnt = torch.empty(3 * NBINS, dtype=torch.int32, device=self.dev)
+        first = torch.empty(3 * NBINS, dtype=torch.int32, device=self.dev)
+        _check(self.L.khg_tile_hist_get(self.c._ctx, _ptr(cnt), _ptr(first), _stream()), "tile_hist_get")
+        return cnt, first
+
+    def hist_set(self, cnt, first):
+        _check(self.L.khg_tile_hist_set(self.c._ctx, _ptr(cnt), _ptr(first), _stream()), "tile_hist_set")
+
+    def lens(self):
+        _check(self.L.khg_tile_lens_dev(self.c._ctx, _stream()), "tile_lens")
+
+    def bits_get(self):
+        rows, cols, world = self.shape
+        bits = torch.empty(self.L.khg_tile_chunk_count(rows, cols, world), dtype=torch.int32, device=self.dev)
+        _check(self.L.khg_tile_bits_get(self.c._ctx, _ptr(bits), _stream()), "tile_bits_get")
+        return bits
+
+    def bits_set(self, bits):
+        _check(self.L.khg_tile_bits_set(self.c._ctx, _ptr(bits), _stream()), "tile_bits_set")
+
+    def pack(self, cap):
+        share = torch.empty(cap, dtype=torch.uint8, device=self.dev)
+        _check(self.L.khg_tile_pack_dev(self.c._ctx, _ptr(share), cap, _stream()), "tile_pack")
+        return share, self.c.encode_result()
+
+    def decode(self, comp, length, rows, cols, rank, world):
+        r0, r1 = tile_rows(rows, rank, world)
+        out = torch.empty((3, r1 - r0, cols), dtype=torch.uint8, device=self.dev)
+        _check(self.L.khg_tile_decode_dev(self.c._ctx, _ptr(comp), length, rows, cols, rank, world, _ptr(out[0]),
+                                          _ptr(out[1]), _ptr(out[2]), _stream()), "tile_decode")
+        st = self.c.last_status_after_decode()
+        if st != 0:
+            raise _lib.KhgError(st, "tile_decode")
+        return out
+
+
+class DistCollectives:
+    """The three collectives over a torch.distributed process group (RCCL on GPUs, gloo on CPUs)."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.on = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+
+    def all_reduce_sum(self, t):
+        if self.on:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+
+    def all_reduce_min(self, t):
+        if self.on:
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+
+    def reduce_sum(self, t, dst):
+        if self.on:
+            dist.reduce(t, dst=dst, op=dist.ReduceOp.SUM, group=self.group)
+
+
+def encode_tiled(backend, strip, rows, cols, lvl, rank, world, coll=None, dst=0):
+    """All ranks call this with their strip (image rows input_rows(rows, rank, world)).  Returns the bytes of the
+    .comp file as a uint8 tensor on rank `dst` (None elsewhere) -- the same bytes a single GPU produces."""
+    coll = coll or DistCollectives()
+    backend.forward(strip, rows, cols, lvl, rank, world)
+    cnt, first = backend.hist_get()
+    # first raster indices: 0xFFFFFFFF (= -1 as int32) marks a symbol this tile never saw; raster indices stay
+    # below 2^31 (checked by the library), so for the MIN reduce the mark becomes the largest int32
+    first = torch.where(first < 0, torch.full_like(first, _ABSENT), first)
+    coll.all_reduce_sum(cnt)
+    coll.all_reduce_min(first)
+    first = torch.where(first == _ABSENT, torch.full_like(first, -1), first)
+    backend.hist_set(cnt, first)
+    backend.lens()
+    bits = backend.bits_get()
+    coll.all_reduce_sum(bits)
+    backend.bits_set(bits)
+    share, total = backend.pack(backend.comp_bound(rows, cols))
+    words = share[: (total + 3) & ~3].view(torch.int32)
+    coll.reduce_sum(words, dst)  # the shares have no set bit in common: their sum is their OR
+    if rank != dst:
+        return None
+    return words.view(torch.uint8)[:total]
+
+
+def decode_tiled(backend, comp, length, rows, cols, rank, world):
+    """comp: the whole file on every rank.  Returns the rank's rows of the picture, (3, rows/world, cols) uint8."""
+    return backend.decode(comp, length, rows, cols, rank, world)

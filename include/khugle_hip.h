@@ -106,6 +106,35 @@ int khg_symbols_dev(khg_ctx *ctx, const uint8_t *d_r, const uint8_t *d_g, const 
 int khg_time_luma_forward_dev(khg_ctx *ctx, const uint8_t *d_r, const uint8_t *d_g, const uint8_t *d_b, int rows,
                               int cols, int lvl, int reps, float *avg_ms, void *stream);
 
+/* ---- one image tiled by rows over several GPUs: one process and one context per GPU, rank t of n owns image
+ * rows [rows*t/n, rows*(t+1)/n), rows a multiple of 8*n, n <= 8.  The reference has a single CompressImage call
+ * (Compress.h:104) for this; the tiled form produces the same bytes.  The steps below do the per-GPU work; between
+ * them the caller runs three collectives on buffers it owns (RCCL in this repository's host layer,
+ * image-compression_amd/python/khugle_amd/tiled.py):
+ *   1. khg_tile_forward_dev   colour + both DWT levels + quantiser on the tile (d_r/d_g/d_b hold image rows
+ *                             row0 .. row1 of khg_tile_input_rows: the tile plus up to 24 halo rows per side)
+ *   2. khg_tile_hist_get  ->  all-reduce SUM of the counts, MIN of the first raster indices (3 x 16384 words
+ *                             each; 0xFFFFFFFF marks "absent")  ->  khg_tile_hist_set
+ *   3. khg_tile_lens_dev      table, tree, codes (Huffman.h:87-139; identical on every rank), bits of own chunks
+ *   4. khg_tile_bits_get  ->  all-reduce SUM over khg_tile_chunk_count words  ->  khg_tile_bits_set
+ *   5. khg_tile_pack_dev      this rank's share of the .comp bytes at their final positions, zero elsewhere
+ *                             (rank 0's share holds the header and tables); khg_encode_result: status, file length
+ *   6. reduce SUM (or OR) of the shares as 32-bit words to the rank that keeps the file.
+ * khg_tile_decode_dev: every rank decodes the whole stream and reconstructs its own rows (Decompress.h:7-126 on
+ * the tile); d_r/d_g/d_b receive exactly the tile's rows. */
+int khg_tile_input_rows(int rows, int rank, int nranks, int *row0, int *row1);
+size_t khg_tile_chunk_count(int rows, int cols, int nranks);
+int khg_tile_forward_dev(khg_ctx *ctx, const uint8_t *d_r, const uint8_t *d_g, const uint8_t *d_b, int rows, int cols,
+                         int lvl, int rank, int nranks, void *stream);
+int khg_tile_hist_get(khg_ctx *ctx, uint32_t *d_count, uint32_t *d_first, void *stream);
+int khg_tile_hist_set(khg_ctx *ctx, const uint32_t *d_count, const uint32_t *d_first, void *stream);
+int khg_tile_lens_dev(khg_ctx *ctx, void *stream);
+int khg_tile_bits_get(khg_ctx *ctx, uint32_t *d_bits, void *stream);
+int khg_tile_bits_set(khg_ctx *ctx, const uint32_t *d_bits, void *stream);
+int khg_tile_pack_dev(khg_ctx *ctx, uint8_t *d_out, size_t cap, void *stream);
+int khg_tile_decode_dev(khg_ctx *ctx, const uint8_t *d_comp, size_t len, int rows, int cols, int rank, int nranks,
+                        uint8_t *d_r, uint8_t *d_g, uint8_t *d_b, void *stream);
+
 /* Measurement aid: while enabled, khg_encode_dev brackets its luma level-1 forward launch with HIP events on
  * the caller's stream, and the kernel notes the device clock at which its first workgroup starts and its last
  * one ends; khg_encode_result adds both durations to per-context tallies that khg_profile_read returns

@@ -53,18 +53,18 @@ void run_fwd(const KhgFwdArgs& a, const KhgFwdGrid& g) {
 }
 
 void forward_all(SimWs& S, const uint8_t* r, const uint8_t* g, const uint8_t* b, int rows, int cols, int lvl,
-                 double* const coef[3]) {
+                 double* const coef[3], KhgTile tile = KhgTile{0, 1}) {
     KhgWorkspace& ws = S.ws;
     memset(ws.hist_cnt, 0, 3 * KHG_NBINS * 4);
     memset(ws.hist_first, 0xFF, 3 * KHG_NBINS * 4);
     memset(ws.res, 0, sizeof(KhgResult));
     KhgFwdGrid gr;
     KhgFwdArgs a;
-    a = khg_fwd_args(ws, r, g, b, rows, cols, lvl, 0, 1, coef ? coef[0] : nullptr, &gr); run_fwd<KHG_SRC_Y, 1>(a, gr);
-    a = khg_fwd_args(ws, r, g, b, rows, cols, lvl, 1, 1, coef ? coef[1] : nullptr, &gr); run_fwd<KHG_SRC_CB, 1>(a, gr);
-    a = khg_fwd_args(ws, r, g, b, rows, cols, lvl, 2, 1, coef ? coef[2] : nullptr, &gr); run_fwd<KHG_SRC_CR, 1>(a, gr);
+    a = khg_fwd_args(ws, r, g, b, rows, cols, lvl, 0, 1, coef ? coef[0] : nullptr, &gr, tile); run_fwd<KHG_SRC_Y, 1>(a, gr);
+    a = khg_fwd_args(ws, r, g, b, rows, cols, lvl, 1, 1, coef ? coef[1] : nullptr, &gr, tile); run_fwd<KHG_SRC_CB, 1>(a, gr);
+    a = khg_fwd_args(ws, r, g, b, rows, cols, lvl, 2, 1, coef ? coef[2] : nullptr, &gr, tile); run_fwd<KHG_SRC_CR, 1>(a, gr);
     for (int c = 0; c < 3; ++c) {
-        a = khg_fwd_args(ws, r, g, b, rows, cols, lvl, c, 2, coef ? coef[c] : nullptr, &gr);
+        a = khg_fwd_args(ws, r, g, b, rows, cols, lvl, c, 2, coef ? coef[c] : nullptr, &gr, tile);
         run_fwd<KHG_SRC_PLANE, 2>(a, gr);
     }
 }
@@ -108,11 +108,9 @@ int khgsim_encode(const uint8_t* r, const uint8_t* g, const uint8_t* b, int rows
     return S.ws.res->status;
 }
 
-// Mirrors khg_decode_dev.
-int khgsim_decode(const uint8_t* comp, size_t len, int rows, int cols, uint8_t* r, uint8_t* g, uint8_t* b,
-                  int16_t* qy, int16_t* qcb, int16_t* qcr, int* passes_used) {
-    if (!khg_dims_ok(rows, cols)) return -1;
-    SimWs S(rows, cols);
+// Mirrors khg_decode_dev / khg_tile_decode_dev (r, g, b receive the tile's rows only).
+static int sim_decode(SimWs& S, const uint8_t* comp, size_t len, int rows, int cols, uint8_t* r, uint8_t* g, uint8_t* b,
+                      int16_t* qy, int16_t* qcb, int16_t* qcr, int* passes_used, KhgTile tile) {
     std::vector<uint8_t> buf((len + 3) & ~(size_t)3, 0);
     memcpy(buf.data(), comp, len);
     KhgDecArgs d = khg_dec_args(S.ws, S.dws, buf.data(), len, rows, cols);
@@ -134,11 +132,11 @@ int khgsim_decode(const uint8_t* comp, size_t len, int rows, int cols, uint8_t* 
     KhgInvSmem* ish = new KhgInvSmem;
     KhgFwdGrid gr;
     for (int p = 0; p < 3; ++p) {
-        KhgInvArgs a = khg_inv_args(S.ws, S.dws, rows, cols, p, 2, &gr);
+        KhgInvArgs a = khg_inv_args(S.ws, S.dws, rows, cols, p, 2, &gr, tile);
         for (int bid = 0; bid < gr.nstrip * gr.nseg; ++bid) khg_inv_strip_body<2>(a, bid, *ish);
     }
     for (int p = 2; p >= 0; --p) {
-        KhgInvArgs a = khg_inv_args(S.ws, S.dws, rows, cols, p, 1, &gr);
+        KhgInvArgs a = khg_inv_args(S.ws, S.dws, rows, cols, p, 1, &gr, tile);
         a.r = r; a.g = g; a.b = b;
         for (int bid = 0; bid < gr.nstrip * gr.nseg; ++bid) {
             if (p == 0) khg_inv_strip_body<1, true>(a, bid, *ish);
@@ -151,6 +149,97 @@ int khgsim_decode(const uint8_t* comp, size_t len, int rows, int cols, uint8_t* 
     if (qcb) memcpy(qcb, S.ws.sym[1], ny / 4 * 2);
     if (qcr) memcpy(qcr, S.ws.sym[2], ny / 4 * 2);
     return S.ws.res->status;
+}
+
+int khgsim_decode(const uint8_t* comp, size_t len, int rows, int cols, uint8_t* r, uint8_t* g, uint8_t* b,
+                  int16_t* qy, int16_t* qcb, int16_t* qcr, int* passes_used) {
+    if (!khg_dims_ok(rows, cols)) return -1;
+    SimWs S(rows, cols);
+    return sim_decode(S, comp, len, rows, cols, r, g, b, qy, qcb, qcr, passes_used, KhgTile{0, 1});
+}
+
+// ---- one rank of a row-tiled image: the steps of khg_tile_* on host memory
+struct SimTile {
+    SimWs S;
+    KhgTile t;
+    int rows, cols, lvl;
+    SimTile(int r, int c) : S(r, c), t{0, 1}, rows(r), cols(c), lvl(0) {}
+};
+
+void* khgsim_tile_create(int rows, int cols) { return khg_dims_ok(rows, cols) ? new SimTile(rows, cols) : nullptr; }
+void khgsim_tile_destroy(void* h) { delete (SimTile*)h; }
+
+size_t khgsim_tile_chunk_count(int rows, int cols, int nranks) {
+    KhgWorkspace none;
+    memset(&none, 0, sizeof none);
+    return khg_enc_args(none, rows, cols, 0, nullptr, 0, KhgTile{0, nranks}).nchunks;
+}
+
+int khgsim_tile_forward(void* h, const uint8_t* r, const uint8_t* g, const uint8_t* b, int rows, int cols, int lvl,
+                        int rank, int nranks) {
+    SimTile* T = (SimTile*)h;
+    KhgTile t = {rank, nranks};
+    if (!khg_tile_ok(rows, t) || rows != T->rows || cols != T->cols) return -1;
+    T->t = t;
+    T->lvl = lvl;
+    forward_all(T->S, r, g, b, rows, cols, lvl, nullptr, t);
+    return T->S.ws.res->status;
+}
+
+void khgsim_tile_hist_get(void* h, uint32_t* cnt, uint32_t* first) {
+    SimTile* T = (SimTile*)h;
+    memcpy(cnt, T->S.ws.hist_cnt, 3 * KHG_NBINS * 4);
+    memcpy(first, T->S.ws.hist_first, 3 * KHG_NBINS * 4);
+}
+
+void khgsim_tile_hist_set(void* h, const uint32_t* cnt, const uint32_t* first) {
+    SimTile* T = (SimTile*)h;
+    memcpy(T->S.ws.hist_cnt, cnt, 3 * KHG_NBINS * 4);
+    memcpy(T->S.ws.hist_first, first, 3 * KHG_NBINS * 4);
+}
+
+void khgsim_tile_lens(void* h) {
+    SimTile* T = (SimTile*)h;
+    KhgTableArgs t = khg_table_args(T->S.ws);
+    KhgTableSmem* tsh = new KhgTableSmem;
+    for (int p = 0; p < 3; ++p) khg_table_body(t, p, *tsh);
+    delete tsh;
+    KhgEncArgs e = khg_enc_args(T->S.ws, T->rows, T->cols, T->lvl, nullptr, 0, T->t);
+    memset(T->S.ws.chunk_bits, 0, (size_t)e.nchunks * 4);
+    KhgLensSmem lsh;
+    for (uint32_t c = 0; c < e.nchunks; ++c) khg_lens_body(e, c, lsh);
+}
+
+void khgsim_tile_bits_get(void* h, uint32_t* bits) {
+    SimTile* T = (SimTile*)h;
+    memcpy(bits, T->S.ws.chunk_bits, khgsim_tile_chunk_count(T->rows, T->cols, T->t.nranks) * 4);
+}
+
+void khgsim_tile_bits_set(void* h, const uint32_t* bits) {
+    SimTile* T = (SimTile*)h;
+    memcpy(T->S.ws.chunk_bits, bits, khgsim_tile_chunk_count(T->rows, T->cols, T->t.nranks) * 4);
+}
+
+int khgsim_tile_pack(void* h, uint8_t* out, size_t cap, size_t* total) {
+    SimTile* T = (SimTile*)h;
+    KhgEncArgs e = khg_enc_args(T->S.ws, T->rows, T->cols, T->lvl, out, cap, T->t);
+    memset(out, 0, cap & ~(size_t)3);
+    KhgScanSmem* ssh = new KhgScanSmem;
+    khg_scan_body(e, *ssh);
+    delete ssh;
+    KhgPackSmem* psh = new KhgPackSmem;
+    for (uint32_t c = 0; c < e.nchunks; ++c) khg_pack_body(e, c, *psh);
+    delete psh;
+    *total = (size_t)T->S.ws.res->total_len;
+    return T->S.ws.res->status;
+}
+
+int khgsim_tile_decode(void* h, const uint8_t* comp, size_t len, int rows, int cols, int rank, int nranks, uint8_t* r,
+                       uint8_t* g, uint8_t* b) {
+    SimTile* T = (SimTile*)h;
+    KhgTile t = {rank, nranks};
+    if (!khg_tile_ok(rows, t) || rows != T->rows || cols != T->cols) return -1;
+    return sim_decode(T->S, comp, len, rows, cols, r, g, b, nullptr, nullptr, nullptr, nullptr, t);
 }
 
 double khgsim_ssim(const uint8_t* a, const uint8_t* b, int width, int height, double* blocks_out) {

@@ -41,6 +41,24 @@ def lib():
         L.khgsim_div_const.restype = None
         L.khgsim_round_quot.argtypes = [_f64p, _f64p, C.c_size_t, _f64p, _u8p]
         L.khgsim_round_quot.restype = None
+        _vp = C.c_void_p
+        L.khgsim_tile_create.argtypes = [C.c_int, C.c_int]
+        L.khgsim_tile_create.restype = _vp
+        L.khgsim_tile_destroy.argtypes = [_vp]
+        L.khgsim_tile_destroy.restype = None
+        L.khgsim_tile_chunk_count.argtypes = [C.c_int, C.c_int, C.c_int]
+        L.khgsim_tile_chunk_count.restype = C.c_size_t
+        L.khgsim_tile_forward.argtypes = [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+        for f in ("hist_get", "hist_set"):
+            getattr(L, "khgsim_tile_" + f).argtypes = [_vp, _vp, _vp]
+            getattr(L, "khgsim_tile_" + f).restype = None
+        L.khgsim_tile_lens.argtypes = [_vp]
+        L.khgsim_tile_lens.restype = None
+        for f in ("bits_get", "bits_set"):
+            getattr(L, "khgsim_tile_" + f).argtypes = [_vp, _vp]
+            getattr(L, "khgsim_tile_" + f).restype = None
+        L.khgsim_tile_pack.argtypes = [_vp, _vp, C.c_size_t, C.POINTER(C.c_size_t)]
+        L.khgsim_tile_decode.argtypes = [_vp, _vp, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]
         _lib = L
     return _lib
 
@@ -97,3 +115,64 @@ def round_quot(x, d):
     out = np.empty_like(x); fast = np.empty(x.size, np.uint8)
     lib().khgsim_round_quot(x, d, x.size, out, fast)
     return out, fast
+
+
+class SimTileBackend:
+    """khugle_amd.tiled backend on the kernel simulator (CPU tensors): one rank of a row-tiled image."""
+
+    def __init__(self, rows, cols):
+        import torch
+        self.torch = torch
+        self.h = lib().khgsim_tile_create(rows, cols)
+        assert self.h
+        self.rows, self.cols = rows, cols
+
+    def __del__(self):
+        try:
+            lib().khgsim_tile_destroy(self.h)
+        except Exception:
+            pass
+
+    def comp_bound(self, rows, cols):
+        return (36 + rows * cols * 3 // 2 * 15 // 8 + 3 * 16384 * 8 + 64) & ~3
+
+    def forward(self, strip, rows, cols, lvl, rank, world):
+        assert strip.dtype == self.torch.uint8 and strip.is_contiguous()
+        self.world = world
+        rc = lib().khgsim_tile_forward(self.h, strip[0].data_ptr(), strip[1].data_ptr(), strip[2].data_ptr(), rows,
+                                       cols, lvl, rank, world)
+        assert rc == 0, rc
+
+    def hist_get(self):
+        t = self.torch
+        cnt = t.empty(3 * 16384, dtype=t.int32); first = t.empty(3 * 16384, dtype=t.int32)
+        lib().khgsim_tile_hist_get(self.h, cnt.data_ptr(), first.data_ptr())
+        return cnt, first
+
+    def hist_set(self, cnt, first):
+        lib().khgsim_tile_hist_set(self.h, cnt.contiguous().data_ptr(), first.contiguous().data_ptr())
+
+    def lens(self):
+        lib().khgsim_tile_lens(self.h)
+
+    def bits_get(self):
+        bits = self.torch.empty(lib().khgsim_tile_chunk_count(self.rows, self.cols, self.world), dtype=self.torch.int32)
+        lib().khgsim_tile_bits_get(self.h, bits.data_ptr())
+        return bits
+
+    def bits_set(self, bits):
+        lib().khgsim_tile_bits_set(self.h, bits.contiguous().data_ptr())
+
+    def pack(self, cap):
+        share = self.torch.empty(cap, dtype=self.torch.uint8)
+        total = C.c_size_t(0)
+        rc = lib().khgsim_tile_pack(self.h, share.data_ptr(), cap, C.byref(total))
+        assert rc == 0, rc
+        return share, total.value
+
+    def decode(self, comp, length, rows, cols, rank, world):
+        out = self.torch.empty((3, rows // world, cols), dtype=self.torch.uint8)
+        rc = lib().khgsim_tile_decode(self.h, comp.data_ptr(), length, rows, cols, rank, world, out[0].data_ptr(),
+                                      out[1].data_ptr(), out[2].data_ptr())
+        assert rc == 0, rc
+        return out

@@ -1,0 +1,114 @@
+"""Row-tiled images on the GPU: n tiles (n contexts on one GPU; ranks as threads, and ranks as gloo processes that
+stage the collectives through the host) give the bytes and the pixels of one encoder.  Through the C ABI."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+sys.path.insert(0, os.path.join(ROOT, "image-compression_amd", "python"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+pytestmark = pytest.mark.gpu
+
+
+def _strip(frame, rows, rank, world):
+    from khugle_amd import tiled
+    i0, i1 = tiled.input_rows(rows, rank, world)
+    return frame[:, i0:i1].contiguous()
+
+
+@pytest.mark.parametrize("shape,world,lvl", [((64, 64), 2, 1), ((256, 264), 8, 0), ((512, 512), 4, 2),
+                                             ((1080, 1920), 3, 1), ((2304, 4096), 8, 1)])
+def test_tiles_on_one_gpu_give_the_bytes_of_one_encoder(codec, shape, world, lvl):
+    from khugle_amd import Codec, tiled
+    from tiledlib import run_ranks
+    rows, cols = shape
+    frame = codec.synth_dev(rows, cols, 2025, 5)
+    want = codec.encode(frame.cpu().numpy(), lvl)
+    full = torch.from_numpy(codec.decode(want)).cuda()
+    ctxs = [Codec(rows, cols) for _ in range(world)]
+
+    def rank_fn(rank, coll):
+        be = tiled.HipTileBackend(ctxs[rank])
+        comp = tiled.encode_tiled(be, _strip(frame, rows, rank, world), rows, cols, lvl, rank, world, coll=coll)
+        torch.cuda.synchronize()
+        return None if comp is None else comp.cpu().numpy().tobytes()
+
+    res = run_ranks(world, rank_fn)
+    assert res[0] == want
+    assert all(r is None for r in res[1:])
+    comp_t = torch.from_numpy(np.frombuffer(want + b"\0" * 8, np.uint8).copy()).cuda()
+    for rank in range(world):
+        tile = tiled.decode_tiled(tiled.HipTileBackend(ctxs[rank]), comp_t, len(want), rows, cols, rank, world)
+        r0, r1 = tiled.tile_rows(rows, rank, world)
+        assert torch.equal(tile, full[:, r0:r1])
+
+
+def test_tile_entry_points_reject_bad_geometry(codec):
+    from khugle_amd import tiled
+    from khugle_amd.lib import KhgError
+    be = tiled.HipTileBackend(codec)
+    frame = codec.synth_dev(72, 64, 1, 0)
+    with pytest.raises(KhgError):  # 72 rows are not a multiple of 8 * 2
+        tiled._check(be.L.khg_tile_forward_dev(codec._ctx, frame[0].data_ptr(), frame[1].data_ptr(),
+                                               frame[2].data_ptr(), 72, 64, 1, 0, 2, None), "tile_forward")
+
+
+class _HostStaged:
+    """Collectives of khugle_amd.tiled for a gloo group: device tensors go through host memory."""
+
+    def _via_host(self, t, fn):
+        h = t.cpu()
+        fn(h)
+        t.copy_(h)
+
+    def all_reduce_sum(self, t):
+        self._via_host(t, lambda h: dist.all_reduce(h, op=dist.ReduceOp.SUM))
+
+    def all_reduce_min(self, t):
+        self._via_host(t, lambda h: dist.all_reduce(h, op=dist.ReduceOp.MIN))
+
+    def reduce_sum(self, t, dst):
+        self._via_host(t, lambda h: dist.reduce(h, dst=dst, op=dist.ReduceOp.SUM))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _gloo_gpu_rank(rank, world, port, rows, cols, lvl, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from khugle_amd import Codec, tiled
+    c = Codec(rows, cols)
+    frame = c.synth_dev(rows, cols, 2025, 9)
+    r0, r1 = tiled.tile_rows(rows, rank, world)
+    own = frame[:, r0:r1].contiguous().cpu()               # what this rank would hold
+    strip = tiled.exchange_halos(own, rank, world).cuda()  # halos from the neighbours (gloo: through the host)
+    comp = tiled.encode_tiled(tiled.HipTileBackend(c), strip, rows, cols, lvl, rank, world, coll=_HostStaged())
+    torch.cuda.synchronize()
+    if rank == 0:
+        with open(out_path, "wb") as f:
+            f.write(comp.cpu().numpy().tobytes())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_processes_on_one_gpu(codec, tmp_path):
+    rows, cols, lvl, world = 512, 768, 1, 2
+    out = str(tmp_path / "tiled.comp")
+    mp.spawn(_gloo_gpu_rank, args=(world, _free_port(), rows, cols, lvl, out), nprocs=world, join=True)
+    want = codec.encode(codec.synth_dev(rows, cols, 2025, 9).cpu().numpy(), lvl)
+    assert open(out, "rb").read() == want

@@ -1,0 +1,100 @@
+"""One image tiled by rows over several ranks: tile invariance (n tiles give the bytes and pixels of one) on the
+kernel simulator, with ranks as threads and as gloo processes; the GPU versions are in test_gpu_tiled.py."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+sys.path.insert(0, os.path.join(ROOT, "image-compression_amd", "python"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def _strip(rgb, rows, rank, world):
+    from khugle_amd import tiled
+    i0, i1 = tiled.input_rows(rows, rank, world)
+    return torch.from_numpy(np.ascontiguousarray(rgb[:, i0:i1]))
+
+
+@pytest.mark.parametrize("shape,world,lvl", [((64, 64), 2, 1), ((128, 72), 2, 0), ((192, 64), 4, 2), ((256, 264), 8, 1)])
+def test_tiles_give_the_bytes_of_one_encoder(shape, world, lvl):
+    from khugle_amd import tiled
+    from khugle_amd.synth import synth_frame
+    import oracle_py as O
+    import simlib as S
+    from tiledlib import run_ranks
+    rows, cols = shape
+    rgb = synth_frame(rows, cols, 7, 3)
+    want = O.encode(rgb, lvl)
+
+    def rank_fn(rank, coll):
+        be = S.SimTileBackend(rows, cols)
+        comp = tiled.encode_tiled(be, _strip(rgb, rows, rank, world), rows, cols, lvl, rank, world, coll=coll)
+        return None if comp is None else comp.numpy().tobytes()
+
+    res = run_ranks(world, rank_fn)
+    assert res[0] == want
+    assert all(r is None for r in res[1:])
+    # decode: every rank reconstructs its rows from the whole file
+    full = O.decode(want)
+    comp_t = torch.from_numpy(np.frombuffer(want + b"\0" * 8, np.uint8).copy())
+    for rank in range(world):
+        be = S.SimTileBackend(rows, cols)
+        tile = tiled.decode_tiled(be, comp_t, len(want), rows, cols, rank, world).numpy()
+        r0, r1 = tiled.tile_rows(rows, rank, world)
+        assert np.array_equal(tile, full[:, r0:r1])
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _gloo_rank(rank, world, port, rows, cols, lvl, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from khugle_amd import tiled
+    from khugle_amd.synth import synth_frame
+    import simlib as S
+    rgb = synth_frame(rows, cols, 11, 0)
+    r0, r1 = tiled.tile_rows(rows, rank, world)
+    own = torch.from_numpy(np.ascontiguousarray(rgb[:, r0:r1]))  # a rank holds its own rows only ...
+    strip = tiled.exchange_halos(own, rank, world)              # ... and gets the halos from its neighbours
+    i0, i1 = tiled.input_rows(rows, rank, world)
+    assert np.array_equal(strip.numpy(), rgb[:, i0:i1])
+    comp = tiled.encode_tiled(S.SimTileBackend(rows, cols), strip, rows, cols, lvl, rank, world)
+    if rank == 0:
+        with open(out_path, "wb") as f:
+            f.write(comp.numpy().tobytes())
+    else:
+        assert comp is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_gloo_ranks_exchange_halos_and_histograms(tmp_path):
+    rows, cols, lvl, world = 128, 96, 1, 2
+    out = str(tmp_path / "tiled.comp")
+    mp.spawn(_gloo_rank, args=(world, _free_port(), rows, cols, lvl, out), nprocs=world, join=True)
+    import oracle_py as O
+    from khugle_amd.synth import synth_frame
+    assert open(out, "rb").read() == O.encode(synth_frame(rows, cols, 11, 0), lvl)
+
+
+def test_tile_geometry():
+    from khugle_amd import tiled
+    assert tiled.tile_rows(256, 1, 4) == (64, 128)
+    assert tiled.input_rows(256, 0, 4) == (0, 88)
+    assert tiled.input_rows(256, 3, 4) == (168, 256)
+    with pytest.raises(ValueError):
+        tiled.tile_rows(100, 0, 2)
