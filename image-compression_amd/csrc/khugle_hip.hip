@@ -48,13 +48,14 @@ __global__ __launch_bounds__(256) void khg_pack_kernel(KhgEncArgs a)
     khg_pack_body(a, blockIdx.x, sh);
 }
 
-__global__ __launch_bounds__(256) void khg_synth_kernel(uint8_t* r, uint8_t* g, uint8_t* b, int rows, int cols,
+// rows x cols pixels of a frame, starting at image row row0.
+__global__ __launch_bounds__(256) void khg_synth_kernel(uint8_t* r, uint8_t* g, uint8_t* b, int row0, int rows, int cols,
                                                         uint32_t seed, uint32_t index)
 {
     size_t n = (size_t)rows * cols;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         uint32_t y = (uint32_t)(i / (size_t)cols), x = (uint32_t)(i - (size_t)y * cols);
-        khg_synth_pixel(y, x, (uint32_t)cols, seed, index, &r[i], &g[i], &b[i]);
+        khg_synth_pixel((uint32_t)row0 + y, x, (uint32_t)cols, seed, index, &r[i], &g[i], &b[i]);
     }
 }
 
@@ -484,13 +485,24 @@ extern "C" int khg_time_luma_forward_dev(khg_ctx* c, const uint8_t* d_r, const u
     return KHG_OK;
 }
 
+extern "C" int khg_synth_rows_dev(uint8_t* d_r, uint8_t* d_g, uint8_t* d_b, int row0, int rows, int cols,
+                                  uint32_t seed, uint32_t index, void* stream);
+
 extern "C" int khg_synth_dev(uint8_t* d_r, uint8_t* d_g, uint8_t* d_b, int rows, int cols, uint32_t seed,
                              uint32_t index, void* stream)
 {
     if (!d_r || !d_g || !d_b || rows <= 0 || cols <= 0) return KHG_ERR_ARG;
+    return khg_synth_rows_dev(d_r, d_g, d_b, 0, rows, cols, seed, index, stream);
+}
+
+extern "C" int khg_synth_rows_dev(uint8_t* d_r, uint8_t* d_g, uint8_t* d_b, int row0, int rows, int cols,
+                                  uint32_t seed, uint32_t index, void* stream)
+{
+    if (!d_r || !d_g || !d_b || row0 < 0 || rows <= 0 || cols <= 0) return KHG_ERR_ARG;
     size_t n = (size_t)rows * cols;
     unsigned grid = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
-    hipLaunchKernelGGL(khg_synth_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_r, d_g, d_b, rows, cols, seed, index);
+    hipLaunchKernelGGL(khg_synth_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_r, d_g, d_b, row0, rows, cols,
+                       seed, index);
     KHG_HIP(hipGetLastError());
     return KHG_OK;
 }

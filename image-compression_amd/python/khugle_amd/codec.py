@@ -141,6 +141,14 @@ class Codec:
                "synth")
         return out
 
+    def synth_rows_dev(self, row0, rows, cols, seed, index):
+        """Rows row0 .. row0+rows-1 of synthetic frame `index` of a `cols`-wide image, (3, rows, cols) uint8."""
+        t = self.torch
+        out = t.empty((3, rows, cols), dtype=t.uint8, device="cuda:%d" % self.device)
+        _check(self.L.khg_synth_rows_dev(_ptr(out[0]), _ptr(out[1]), _ptr(out[2]), row0, rows, cols, seed, index,
+                                         _stream()), "synth_rows")
+        return out
+
     # ---- host-buffer API (synchronous; the library stages through its own device buffers)
     def encode(self, rgb, lvl):
         """rgb: (3, H, W) uint8 numpy -> bytes of the .comp file."""

@@ -62,6 +62,7 @@ SYMBOLS = [
     ("khg_forward_planes_dev", C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P]),
     ("khg_symbols_dev", C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P]),
     ("khg_time_luma_forward_dev", C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), _P]),
+    ("khg_synth_rows_dev", C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_uint32, _P]),
     ("khg_synth_dev", C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_uint32, C.c_uint32, _P]),
 ]
 

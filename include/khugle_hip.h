@@ -148,6 +148,9 @@ int khg_profile_read(khg_ctx *ctx, double *total_ms, double *total_device_ms, in
  * khugle_amd.synth.synth_frame on the host.  Device planes. */
 int khg_synth_dev(uint8_t *d_r, uint8_t *d_g, uint8_t *d_b, int rows, int cols, uint32_t seed, uint32_t index,
                   void *stream);
+/* Rows row0 .. row0+rows-1 of the same frame (a tile of a large image is generated where it is used). */
+int khg_synth_rows_dev(uint8_t *d_r, uint8_t *d_g, uint8_t *d_b, int row0, int rows, int cols, uint32_t seed,
+                       uint32_t index, void *stream);
 
 #ifdef __cplusplus
 }

@@ -51,6 +51,11 @@ def test_tiles_on_one_gpu_give_the_bytes_of_one_encoder(codec, shape, world, lvl
         assert torch.equal(tile, full[:, r0:r1])
 
 
+def test_tile_generator_matches_the_frame(codec):
+    frame = codec.synth_dev(264, 520, 2025, 3)
+    assert torch.equal(codec.synth_rows_dev(40, 96, 520, 2025, 3), frame[:, 40:136])
+
+
 def test_tile_entry_points_reject_bad_geometry(codec):
     from khugle_amd import tiled
     from khugle_amd.lib import KhgError
