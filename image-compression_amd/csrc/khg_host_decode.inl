@@ -28,13 +28,14 @@ extern "C" int khg_peek(const uint8_t* comp, size_t len, khg_header* hdr)
     return KHG_OK;
 }
 
+// ycbcr != null: stop before the colour conversion and leave the f64 planes there (DecompressImage's outputs).
 static int khg_decode_enqueue(khg_ctx* c, const uint8_t* d_comp, size_t len, int rows, int cols, uint8_t* d_r,
-                              uint8_t* d_g, uint8_t* d_b, void* stream, KhgTile tile)
+                              uint8_t* d_g, uint8_t* d_b, void* stream, KhgTile tile, double* const ycbcr[3] = nullptr)
 {
     int rc = khg_check_image(c, rows, cols);
     if (rc) return rc;
-    if (!d_comp || !d_r || !d_g || !d_b || ((uintptr_t)d_comp & 3) || ((uintptr_t)d_r & 7) || ((uintptr_t)d_g & 7) ||
-        ((uintptr_t)d_b & 7))
+    if (!d_comp || ((uintptr_t)d_comp & 3)) return KHG_ERR_ARG;
+    if (!ycbcr && (!d_r || !d_g || !d_b || ((uintptr_t)d_r & 7) || ((uintptr_t)d_g & 7) || ((uintptr_t)d_b & 7)))
         return KHG_ERR_ARG;
     if (len < 36 + 24) return KHG_ERR_FORMAT;
     hipStream_t st = (hipStream_t)stream;
@@ -53,7 +54,10 @@ static int khg_decode_enqueue(khg_ctx* c, const uint8_t* d_comp, size_t len, int
     }
     for (int p = 2; p >= 0; --p) {  // Decompress.h:278-280; luma last: it also does Decompress.h:282 + Main.cpp:307-315
         KhgInvArgs a = khg_inv_args(c->ws, c->dws, rows, cols, p, 1, &gr, tile);
-        if (p == 0) {
+        if (ycbcr) {
+            a.dst = ycbcr[p];
+            hipLaunchKernelGGL((khg_inv_kernel<1, false>), dim3(gr.nstrip * gr.nseg), dim3(256), 0, st, a);
+        } else if (p == 0) {
             a.r = d_r; a.g = d_g; a.b = d_b;
             hipLaunchKernelGGL((khg_inv_kernel<1, true>), dim3(gr.nstrip * gr.nseg), dim3(256), 0, st, a);
         } else {
@@ -72,6 +76,14 @@ extern "C" int khg_decode_dev(khg_ctx* c, const uint8_t* d_comp, size_t len, int
                               uint8_t* d_g, uint8_t* d_b, void* stream)
 {
     return khg_decode_enqueue(c, d_comp, len, rows, cols, d_r, d_g, d_b, stream, KhgTile{0, 1});
+}
+
+extern "C" int khg_decode_ycbcr_dev(khg_ctx* c, const uint8_t* d_comp, size_t len, int rows, int cols, double* d_y,
+                                    double* d_cb, double* d_cr, void* stream)
+{
+    if (!d_y || !d_cb || !d_cr) return KHG_ERR_ARG;
+    double* planes[3] = {d_y, d_cb, d_cr};
+    return khg_decode_enqueue(c, d_comp, len, rows, cols, nullptr, nullptr, nullptr, stream, KhgTile{0, 1}, planes);
 }
 
 extern "C" int khg_last_status(khg_ctx* c)
@@ -104,6 +116,72 @@ extern "C" int khg_decode(khg_ctx* c, const uint8_t* comp, size_t len, uint8_t* 
     KHG_HIP(hipMemcpy(r, d, n, hipMemcpyDeviceToHost));
     KHG_HIP(hipMemcpy(g, d + n, n, hipMemcpyDeviceToHost));
     KHG_HIP(hipMemcpy(b, d + 2 * n, n, hipMemcpyDeviceToHost));
+    return KHG_OK;
+}
+
+// ---- host-pointer forms of the f64 plane entry points: CompressImage (Compress.h:104) and DecompressImage
+// (Decompress.h:7) as the reference calls them, on contiguous planes.
+static int khg_stage_f64(khg_ctx* c)
+{
+    if (c->stage_f64) return KHG_OK;
+    size_t n = (size_t)c->max_rows * c->max_cols;
+    if (hipMalloc((void**)&c->stage_f64, 2 * (n + n / 2) * sizeof(double)) != hipSuccess) return KHG_ERR_NOMEM;
+    return KHG_OK;
+}
+
+extern "C" int khg_encode_ycbcr(khg_ctx* c, double* y, double* cb, double* cr, int rows, int cols, int lvl,
+                                uint8_t* out, size_t cap, size_t* out_len, int write_back)
+{
+    int rc = khg_check_image(c, rows, cols);
+    if (rc) return rc;
+    if (!y || !cb || !cr || !out) return KHG_ERR_ARG;
+    KHG_HIP(hipSetDevice(c->device));
+    const size_t n = (size_t)rows * cols, nc = n / 4;
+    size_t dcap = khg_comp_bound_impl(rows, cols);
+    if ((rc = khg_stage(c, dcap)) || (rc = khg_stage_f64(c))) return rc;
+    double* in[3] = {c->stage_f64, c->stage_f64 + n, c->stage_f64 + n + nc};
+    double* co[3] = {in[2] + nc, in[2] + nc + n, in[2] + nc + n + nc};
+    KHG_HIP(hipMemcpy(in[0], y, n * 8, hipMemcpyHostToDevice));
+    KHG_HIP(hipMemcpy(in[1], cb, nc * 8, hipMemcpyHostToDevice));
+    KHG_HIP(hipMemcpy(in[2], cr, nc * 8, hipMemcpyHostToDevice));
+    rc = khg_encode_ycbcr_dev(c, in[0], in[1], in[2], rows, cols, lvl, c->stage_comp, dcap, write_back ? co[0] : nullptr,
+                              write_back ? co[1] : nullptr, write_back ? co[2] : nullptr, nullptr);
+    if (rc) return rc;
+    size_t len = 0;
+    rc = khg_encode_result(c, &len);
+    if (rc) return rc;
+    if (len > cap) return KHG_ERR_CAP;
+    KHG_HIP(hipMemcpy(out, c->stage_comp, len, hipMemcpyDeviceToHost));
+    if (write_back) {  // CompressImage leaves the DWT coefficients in its input planes (Compress.h:108-114)
+        KHG_HIP(hipMemcpy(y, co[0], n * 8, hipMemcpyDeviceToHost));
+        KHG_HIP(hipMemcpy(cb, co[1], nc * 8, hipMemcpyDeviceToHost));
+        KHG_HIP(hipMemcpy(cr, co[2], nc * 8, hipMemcpyDeviceToHost));
+    }
+    if (out_len) *out_len = len;
+    return KHG_OK;
+}
+
+extern "C" int khg_decode_ycbcr(khg_ctx* c, const uint8_t* comp, size_t len, double* y, double* cb, double* cr)
+{
+    if (!c || !comp || !y || !cb || !cr) return KHG_ERR_ARG;
+    khg_header hd;
+    int rc = khg_peek(comp, len, &hd);
+    if (rc) return rc;
+    rc = khg_check_image(c, hd.h, hd.w);
+    if (rc) return rc;
+    KHG_HIP(hipSetDevice(c->device));
+    const size_t n = (size_t)hd.h * hd.w, nc = n / 4;
+    size_t padded = (len + 3) & ~(size_t)3;
+    if ((rc = khg_stage(c, padded)) || (rc = khg_stage_f64(c))) return rc;
+    KHG_HIP(hipMemcpy(c->stage_comp, comp, len, hipMemcpyHostToDevice));
+    double* d[3] = {c->stage_f64, c->stage_f64 + n, c->stage_f64 + n + nc};
+    rc = khg_decode_ycbcr_dev(c, c->stage_comp, len, hd.h, hd.w, d[0], d[1], d[2], nullptr);
+    if (rc) return rc;
+    rc = khg_last_status(c);
+    if (rc) return rc;
+    KHG_HIP(hipMemcpy(y, d[0], n * 8, hipMemcpyDeviceToHost));
+    KHG_HIP(hipMemcpy(cb, d[1], nc * 8, hipMemcpyDeviceToHost));
+    KHG_HIP(hipMemcpy(cr, d[2], nc * 8, hipMemcpyDeviceToHost));
     return KHG_OK;
 }
 

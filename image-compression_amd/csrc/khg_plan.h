@@ -172,7 +172,8 @@ static inline int khg_tile_in_row1(int rows, KhgTile t)
 // khg_tile_in_row0().  Every output is a fixed expression of the inputs, so the recomputed rows are bit-exact.
 static inline KhgFwdArgs khg_fwd_args(const KhgWorkspace& ws, const uint8_t* r, const uint8_t* g, const uint8_t* b,
                                       int rows, int cols, int lvl, int comp, int level, double* coef,
-                                      KhgFwdGrid* grid, KhgTile tile = KhgTile{0, 1})
+                                      KhgFwdGrid* grid, KhgTile tile = KhgTile{0, 1},
+                                      const double* const ycbcr[3] = nullptr)
 {
     KhgFwdArgs a;
     memset(&a, 0, sizeof a);
@@ -181,6 +182,10 @@ static inline KhgFwdArgs khg_fwd_args(const KhgWorkspace& ws, const uint8_t* r, 
     a.img_w = cols;
     if (level == 1) {
         a.ph = prow; a.pw = pcol;
+        if (ycbcr) {  // level 1 from caller-supplied f64 Y / Cb / Cr planes instead of RGB (KHG_SRC_PLANE)
+            a.src = ycbcr[comp];
+            a.src_pitch = pcol;
+        }
     } else {
         a.ph = prow / 2; a.pw = pcol / 2;
         a.src = ws.ll[comp];

@@ -146,6 +146,7 @@ struct khg_ctx {
     uint8_t* stage_rgb;  // 3 planes
     uint8_t* stage_comp;
     size_t stage_comp_bytes;
+    double* stage_f64;   // 2 x (Y + Cb + Cr) f64 planes for the host YCbCr entry points
     double* ssim_blocks; // per-block SSIM values
     double* h_ssim_blocks;
     unsigned long long* sse; // [3] sums of squared errors
@@ -249,6 +250,7 @@ extern "C" void khg_ctx_destroy(khg_ctx* c)
     if (c->stage_comp) (void)hipFree(c->stage_comp);
     if (c->h_res) (void)hipHostFree(c->h_res);
     if (c->h_ssim_blocks) (void)hipHostFree(c->h_ssim_blocks);
+    if (c->stage_f64) (void)hipFree(c->stage_f64);
     if (c->done) (void)hipEventDestroy(c->done);
     if (c->prof_e0) (void)hipEventDestroy(c->prof_e0);
     if (c->prof_e1) (void)hipEventDestroy(c->prof_e1);
@@ -309,6 +311,42 @@ extern "C" int khg_profile_read(khg_ctx* c, double* total_ms, double* total_devi
     return KHG_OK;
 }
 
+// Same from f64 Y / Cb / Cr planes (what CompressImage receives, Compress.h:104-114).
+static int khg_enqueue_forward_ycbcr(khg_ctx* c, const double* const ycbcr[3], int rows, int cols, int lvl,
+                                     double* const coef[3], hipStream_t st)
+{
+    KhgWorkspace& ws = c->ws;
+    KHG_HIP(hipMemsetAsync(ws.hist_cnt, 0, 3 * KHG_NBINS * sizeof(uint32_t), st));
+    KHG_HIP(hipMemsetAsync(ws.hist_first, 0xFF, 3 * KHG_NBINS * sizeof(uint32_t), st));
+    KHG_HIP(hipMemsetAsync(ws.res, 0, sizeof(KhgResult), st));
+    KhgFwdGrid gr;
+    for (int level = 1; level <= 2; ++level)
+        for (int p = 0; p < 3; ++p) {
+            KhgFwdArgs a = khg_fwd_args(ws, nullptr, nullptr, nullptr, rows, cols, lvl, p, level,
+                                        coef ? coef[p] : nullptr, &gr, KhgTile{0, 1}, level == 1 ? ycbcr : nullptr);
+            if (level == 1) khg_launch_fwd<KHG_SRC_PLANE, 1>(a, gr, st);
+            else khg_launch_fwd<KHG_SRC_PLANE, 2>(a, gr, st);
+        }
+    KHG_HIP(hipGetLastError());
+    return KHG_OK;
+}
+
+static int khg_enqueue_entropy(khg_ctx* c, int rows, int cols, int lvl, uint8_t* d_out, size_t cap, hipStream_t st)
+{
+    KhgTableArgs t = khg_table_args(c->ws);
+    hipLaunchKernelGGL(khg_table_kernel, dim3(3), dim3(256), 0, st, t);
+    KhgEncArgs e = khg_enc_args(c->ws, rows, cols, lvl, d_out, cap);
+    hipLaunchKernelGGL(khg_lens_kernel, dim3(e.nchunks), dim3(256), 0, st, e);
+    hipLaunchKernelGGL(khg_scan_kernel, dim3(1), dim3(1024), 0, st, e);
+    hipLaunchKernelGGL(khg_pack_kernel, dim3(e.nchunks), dim3(256), 0, st, e);
+    KHG_HIP(hipGetLastError());
+    KHG_HIP(hipMemcpyAsync(c->h_res, c->ws.res, sizeof(KhgResult), hipMemcpyDeviceToHost, st));
+    KHG_HIP(hipEventRecord(c->done, st));
+    c->last_stream = st;
+    c->pending = 1;
+    return KHG_OK;
+}
+
 static int khg_enqueue_forward(khg_ctx* c, const uint8_t* r, const uint8_t* g, const uint8_t* b, int rows, int cols,
                                int lvl, double* const coef[3], hipStream_t st, KhgTile tile = KhgTile{0, 1})
 {
@@ -352,18 +390,26 @@ extern "C" int khg_encode_dev(khg_ctx* c, const uint8_t* d_r, const uint8_t* d_g
     KHG_HIP(hipSetDevice(c->device));
     rc = khg_enqueue_forward(c, d_r, d_g, d_b, rows, cols, lvl, nullptr, st);
     if (rc) return rc;
-    KhgTableArgs t = khg_table_args(c->ws);
-    hipLaunchKernelGGL(khg_table_kernel, dim3(3), dim3(256), 0, st, t);
-    KhgEncArgs e = khg_enc_args(c->ws, rows, cols, lvl, d_out, cap);
-    hipLaunchKernelGGL(khg_lens_kernel, dim3(e.nchunks), dim3(256), 0, st, e);
-    hipLaunchKernelGGL(khg_scan_kernel, dim3(1), dim3(1024), 0, st, e);
-    hipLaunchKernelGGL(khg_pack_kernel, dim3(e.nchunks), dim3(256), 0, st, e);
-    KHG_HIP(hipGetLastError());
-    KHG_HIP(hipMemcpyAsync(c->h_res, c->ws.res, sizeof(KhgResult), hipMemcpyDeviceToHost, st));
-    KHG_HIP(hipEventRecord(c->done, st));
-    c->last_stream = st;
-    c->pending = 1;
-    return KHG_OK;
+    return khg_enqueue_entropy(c, rows, cols, lvl, d_out, cap, st);
+}
+
+extern "C" int khg_encode_ycbcr_dev(khg_ctx* c, const double* d_y, const double* d_cb, const double* d_cr, int rows,
+                                    int cols, int lvl, uint8_t* d_out, size_t cap, double* d_coef_y,
+                                    double* d_coef_cb, double* d_coef_cr, void* stream)
+{
+    int rc = khg_check_image(c, rows, cols);
+    if (rc) return rc;
+    if (lvl < 0 || lvl > 2) return KHG_ERR_DIMS;
+    if (!d_y || !d_cb || !d_cr || !d_out || ((uintptr_t)d_out & 3)) return KHG_ERR_ARG;
+    if (cap < 40) return KHG_ERR_CAP;
+    hipStream_t st = (hipStream_t)stream;
+    KHG_HIP(hipSetDevice(c->device));
+    const double* src[3] = {d_y, d_cb, d_cr};
+    double* coef[3] = {d_coef_y, d_coef_cb, d_coef_cr};
+    const bool tap = d_coef_y && d_coef_cb && d_coef_cr;
+    rc = khg_enqueue_forward_ycbcr(c, src, rows, cols, lvl, tap ? coef : nullptr, st);
+    if (rc) return rc;
+    return khg_enqueue_entropy(c, rows, cols, lvl, d_out, cap, st);
 }
 
 extern "C" int khg_encode_result(khg_ctx* c, size_t* out_len)

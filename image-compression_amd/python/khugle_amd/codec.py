@@ -163,6 +163,28 @@ class Codec:
                                  out.ctypes.data, cap, C.byref(n)), "encode")
         return out[:n.value].tobytes()
 
+    def encode_ycbcr(self, y, cb, cr, lvl, write_back=False):
+        """CompressImage's own inputs: f64 planes (Y HxW, Cb / Cr H/2 x W/2) -> bytes of the .comp file.
+        write_back=True also returns the DWT coefficient planes CompressImage leaves in its inputs."""
+        y = np.array(y, np.float64, order="C"); cb = np.array(cb, np.float64, order="C"); cr = np.array(cr, np.float64, order="C")
+        h, w = y.shape
+        cap = self.L.khg_comp_bound(h, w)
+        out = np.empty(cap, np.uint8)
+        n = C.c_size_t(0)
+        _check(self.L.khg_encode_ycbcr(self._ctx, y.ctypes.data, cb.ctypes.data, cr.ctypes.data, h, w, lvl,
+                                       out.ctypes.data, cap, C.byref(n), 1 if write_back else 0), "encode_ycbcr")
+        comp = out[:n.value].tobytes()
+        return (comp, (y, cb, cr)) if write_back else comp
+
+    def decode_ycbcr(self, comp):
+        """DecompressImage's own outputs: bytes of a .comp file -> f64 planes Y, Cb, Cr."""
+        buf = np.frombuffer(comp, np.uint8)
+        hd = peek(comp)
+        y = np.empty((hd.h, hd.w)); cb = np.empty((hd.h // 2, hd.w // 2)); cr = np.empty((hd.h // 2, hd.w // 2))
+        _check(self.L.khg_decode_ycbcr(self._ctx, buf.ctypes.data, buf.size, y.ctypes.data, cb.ctypes.data,
+                                       cr.ctypes.data), "decode_ycbcr")
+        return y, cb, cr
+
     def decode(self, comp):
         """bytes of a .comp file -> (3, H, W) uint8 numpy."""
         buf = np.frombuffer(comp, np.uint8)

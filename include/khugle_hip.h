@@ -83,6 +83,20 @@ int khg_decode_dev(khg_ctx *ctx, const uint8_t *d_comp, size_t len, int rows, in
 /* Waits for the context's last enqueued work and returns its device-side status. */
 int khg_last_status(khg_ctx *ctx);
 
+/* ---- the reference's own entry points, which work on f64 Y / Cb / Cr planes (Y rows x cols, Cb and Cr
+ * rows/2 x cols/2, contiguous): CompressImage (Compress.h:104-408) without RGB2YCbCr in front, and DecompressImage
+ * (Decompress.h:7-126, 274-280) without YCbCr2RGB behind.  write_back != 0 leaves the DWT coefficients in the input
+ * planes as CompressImage does (Compress.h:108-114).  The *_dev forms take device pointers (optional coefficient
+ * planes, all three or none) and are asynchronous like khg_encode_dev / khg_decode_dev. */
+int khg_encode_ycbcr(khg_ctx *ctx, double *y, double *cb, double *cr, int rows, int cols, int lvl, uint8_t *out,
+                     size_t cap, size_t *out_len, int write_back);
+int khg_decode_ycbcr(khg_ctx *ctx, const uint8_t *comp, size_t len, double *y, double *cb, double *cr);
+int khg_encode_ycbcr_dev(khg_ctx *ctx, const double *d_y, const double *d_cb, const double *d_cr, int rows, int cols,
+                         int lvl, uint8_t *d_out, size_t cap, double *d_coef_y, double *d_coef_cb, double *d_coef_cr,
+                         void *stream);
+int khg_decode_ycbcr_dev(khg_ctx *ctx, const uint8_t *d_comp, size_t len, int rows, int cols, double *d_y, double *d_cb,
+                         double *d_cr, void *stream);
+
 /* ---- quality metrics: ComputeSSIM (SSIM.h:57-72; the application passes the R channel only,
  * Main.cpp:250-253) and GetPsnr (KhuGleBase.cpp:613-627).  Device planes, synchronous result.
  * Per-block SSIM values are bit-exact; *ssim is their sum in raster order divided by the count. */

@@ -138,6 +138,14 @@ def decode(comp):
     return out
 
 
+def rgb_to_ycbcr(rgb):
+    """Colorspace.h:5-23 on u8 planes: Y full size, Cb / Cr at even rows and columns."""
+    r, g, b, h, w = _planes(rgb)
+    y = np.zeros((h, w)); cb = np.zeros((h // 2, w // 2)); cr = np.zeros((h // 2, w // 2))
+    lib().khgo_rgb_to_ycbcr(r, g, b, h, w, y, cb, cr)
+    return y, cb, cr
+
+
 def forward_planes(rgb):
     r, g, b, h, w = _planes(rgb)
     y = np.zeros((h, w)); cb = np.zeros((h // 2, w // 2)); cr = np.zeros((h // 2, w // 2))

@@ -108,9 +108,10 @@ int khgsim_encode(const uint8_t* r, const uint8_t* g, const uint8_t* b, int rows
     return S.ws.res->status;
 }
 
-// Mirrors khg_decode_dev / khg_tile_decode_dev (r, g, b receive the tile's rows only).
+// Mirrors khg_decode_dev / khg_tile_decode_dev (r, g, b receive the tile's rows only) / khg_decode_ycbcr_dev.
 static int sim_decode(SimWs& S, const uint8_t* comp, size_t len, int rows, int cols, uint8_t* r, uint8_t* g, uint8_t* b,
-                      int16_t* qy, int16_t* qcb, int16_t* qcr, int* passes_used, KhgTile tile) {
+                      int16_t* qy, int16_t* qcb, int16_t* qcr, int* passes_used, KhgTile tile,
+                      double* const ycbcr[3] = nullptr) {
     std::vector<uint8_t> buf((len + 3) & ~(size_t)3, 0);
     memcpy(buf.data(), comp, len);
     KhgDecArgs d = khg_dec_args(S.ws, S.dws, buf.data(), len, rows, cols);
@@ -138,8 +139,9 @@ static int sim_decode(SimWs& S, const uint8_t* comp, size_t len, int rows, int c
     for (int p = 2; p >= 0; --p) {
         KhgInvArgs a = khg_inv_args(S.ws, S.dws, rows, cols, p, 1, &gr, tile);
         a.r = r; a.g = g; a.b = b;
+        if (ycbcr) a.dst = ycbcr[p];
         for (int bid = 0; bid < gr.nstrip * gr.nseg; ++bid) {
-            if (p == 0) khg_inv_strip_body<1, true>(a, bid, *ish);
+            if (p == 0 && !ycbcr) khg_inv_strip_body<1, true>(a, bid, *ish);
             else khg_inv_strip_body<1, false>(a, bid, *ish);
         }
     }
@@ -156,6 +158,50 @@ int khgsim_decode(const uint8_t* comp, size_t len, int rows, int cols, uint8_t* 
     if (!khg_dims_ok(rows, cols)) return -1;
     SimWs S(rows, cols);
     return sim_decode(S, comp, len, rows, cols, r, g, b, qy, qcb, qcr, passes_used, KhgTile{0, 1});
+}
+
+// Mirrors khg_encode_ycbcr_dev / khg_decode_ycbcr_dev.
+int khgsim_encode_ycbcr(const double* y, const double* cb, const double* cr, int rows, int cols, int lvl, uint8_t* out,
+                        size_t cap, size_t* out_len, double* coef_y, double* coef_cb, double* coef_cr) {
+    if (!khg_dims_ok(rows, cols) || lvl < 0 || lvl > 2) return -1;
+    SimWs S(rows, cols);
+    KhgWorkspace& ws = S.ws;
+    memset(ws.hist_cnt, 0, 3 * KHG_NBINS * 4);
+    memset(ws.hist_first, 0xFF, 3 * KHG_NBINS * 4);
+    memset(ws.res, 0, sizeof(KhgResult));
+    const double* src[3] = {y, cb, cr};
+    double* coef[3] = {coef_y, coef_cb, coef_cr};
+    KhgFwdGrid gr;
+    for (int level = 1; level <= 2; ++level)
+        for (int p = 0; p < 3; ++p) {
+            KhgFwdArgs a = khg_fwd_args(ws, nullptr, nullptr, nullptr, rows, cols, lvl, p, level, coef_y ? coef[p] : nullptr,
+                                        &gr, KhgTile{0, 1}, level == 1 ? src : nullptr);
+            if (level == 1) run_fwd<KHG_SRC_PLANE, 1>(a, gr);
+            else run_fwd<KHG_SRC_PLANE, 2>(a, gr);
+        }
+    KhgTableArgs t = khg_table_args(ws);
+    KhgTableSmem* tsh = new KhgTableSmem;
+    for (int p = 0; p < 3; ++p) khg_table_body(t, p, *tsh);
+    delete tsh;
+    KhgEncArgs e = khg_enc_args(ws, rows, cols, lvl, out, cap);
+    KhgLensSmem lsh;
+    for (uint32_t c = 0; c < e.nchunks; ++c) khg_lens_body(e, c, lsh);
+    KhgScanSmem* ssh = new KhgScanSmem;
+    khg_scan_body(e, *ssh);
+    delete ssh;
+    KhgPackSmem* psh = new KhgPackSmem;
+    for (uint32_t c = 0; c < e.nchunks; ++c) khg_pack_body(e, c, *psh);
+    delete psh;
+    if (out_len) *out_len = (size_t)ws.res->total_len;
+    return ws.res->status;
+}
+
+int khgsim_decode_ycbcr(const uint8_t* comp, size_t len, int rows, int cols, double* y, double* cb, double* cr) {
+    if (!khg_dims_ok(rows, cols)) return -1;
+    SimWs S(rows, cols);
+    double* planes[3] = {y, cb, cr};
+    return sim_decode(S, comp, len, rows, cols, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                      KhgTile{0, 1}, planes);
 }
 
 // ---- one rank of a row-tiled image: the steps of khg_tile_* on host memory

@@ -42,6 +42,9 @@ def lib():
         L.khgsim_round_quot.argtypes = [_f64p, _f64p, C.c_size_t, _f64p, _u8p]
         L.khgsim_round_quot.restype = None
         _vp = C.c_void_p
+        L.khgsim_encode_ycbcr.argtypes = [_f64p, _f64p, _f64p, C.c_int, C.c_int, C.c_int, _u8p, C.c_size_t,
+                                          C.POINTER(C.c_size_t), C.c_void_p, C.c_void_p, C.c_void_p]
+        L.khgsim_decode_ycbcr.argtypes = [_u8p, C.c_size_t, C.c_int, C.c_int, _f64p, _f64p, _f64p]
         L.khgsim_tile_create.argtypes = [C.c_int, C.c_int]
         L.khgsim_tile_create.restype = _vp
         L.khgsim_tile_destroy.argtypes = [_vp]
@@ -176,3 +179,22 @@ class SimTileBackend:
                                       out[1].data_ptr(), out[2].data_ptr())
         assert rc == 0, rc
         return out
+
+
+def encode_ycbcr(y, cb, cr, lvl, want_coef=False):
+    y = np.ascontiguousarray(y, np.float64); cb = np.ascontiguousarray(cb, np.float64); cr = np.ascontiguousarray(cr, np.float64)
+    rows, cols = y.shape
+    cap = (36 + rows * cols * 3 + 3 * 16384 * 8 + 64) & ~3
+    out = np.zeros(cap, np.uint8)
+    n = C.c_size_t(0)
+    co = [np.zeros_like(p) for p in (y, cb, cr)] if want_coef else [None] * 3
+    rc = lib().khgsim_encode_ycbcr(y, cb, cr, rows, cols, lvl, out, cap, C.byref(n),
+                                   *[c.ctypes.data if c is not None else None for c in co])
+    return rc, out[:n.value].tobytes(), co
+
+
+def decode_ycbcr(comp, rows, cols):
+    buf = np.frombuffer(comp, np.uint8).copy()
+    y = np.zeros((rows, cols)); cb = np.zeros((rows // 2, cols // 2)); cr = np.zeros((rows // 2, cols // 2))
+    rc = lib().khgsim_decode_ycbcr(buf, buf.size, rows, cols, y, cb, cr)
+    return rc, y, cb, cr

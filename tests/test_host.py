@@ -81,3 +81,18 @@ def test_cli_parses_and_fails_loudly_without_a_gpu(tmp_path):
         with pytest.raises((khg_lib.KhgError, RuntimeError, OSError)):
             harness.main(["compress", bmp, str(tmp_path / "x.comp")])
         assert not os.path.exists(str(tmp_path / "x.comp"))
+
+
+def test_dropin_driver_fails_loudly_without_a_gpu(tmp_path):
+    """The C++ drop-in header has no CPU path either: its driver must report the library's error and exit 1."""
+    import subprocess
+    import torch
+    driver = os.path.join(ROOT, "tests", "host", "dropin_main")
+    if not os.path.exists(driver) or torch.cuda.is_available():
+        pytest.skip("driver not built, or a GPU is present")
+    raw = str(tmp_path / "z.raw")
+    np.zeros(3 * 64 * 64, np.uint8).tofile(raw)
+    r = subprocess.run([driver, "64", "64", "1", raw, str(tmp_path / "z.comp"), str(tmp_path / "c"), str(tmp_path / "p")],
+                       capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "khg_ctx_create" in r.stderr
+    assert not os.path.exists(str(tmp_path / "z.comp"))

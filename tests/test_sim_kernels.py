@@ -132,3 +132,20 @@ def test_quantiser_rounding_shortcut():
     assert fast.mean() > 0.999  # the division is the rare path
     got, fast = S.round_quot(half, d)
     assert fast.sum() == 0
+
+
+@pytest.mark.parametrize("shape,lvl", [((64, 64), 1), ((72, 136), 0), ((264, 520), 2)])
+def test_ycbcr_plane_entry_points(shape, lvl):
+    """CompressImage / DecompressImage as the reference calls them: f64 Y, Cb, Cr planes in, .comp bytes out (and
+    the DWT coefficients left behind), and back to f64 planes."""
+    rgb = synth_frame(shape[0], shape[1], 5, 1)
+    y, cb, cr = O.rgb_to_ycbcr(rgb)
+    rc, comp, coef = S.encode_ycbcr(y, cb, cr, lvl, want_coef=True)
+    assert rc == 0
+    assert comp == O.encode(rgb, lvl)
+    for got, want in zip(coef, O.forward_planes(rgb)):
+        assert np.array_equal(got, want)
+    rc, dy, dcb, dcr = S.decode_ycbcr(comp, shape[0], shape[1])
+    assert rc == 0
+    _, (wy, wcb, wcr) = O.decode_planes(comp)
+    assert np.array_equal(dy, wy) and np.array_equal(dcb, wcb) and np.array_equal(dcr, wcr)
