@@ -65,3 +65,19 @@ def long_code_comp(rows, cols, lvl, depth=30, seed=0):
     seq[rng.choice(n, 4 * (depth + 1), replace=False)] = np.tile(syms, 4)  # every code length shows up
     zero = (np.array([n // 4], np.int32), np.array([0], np.int32), [])
     return make_comp(rows, cols, lvl, [(counts.astype(np.int32), syms, seq), zero, zero])
+
+
+def stress_images(h, w):
+    """Pictures that push the path to its corners: one flat colour (single-entry tables, empty streams), white
+    noise (hundreds of symbols, long codes, large detail coefficients), a black/white checkerboard (the largest
+    high-pass values 8-bit input can produce) and vertical bars of extreme colours (large chroma)."""
+    import numpy as np
+    rng = np.random.default_rng(h * 1000 + w)
+    yy, xx = np.mgrid[0:h, 0:w]
+    flat = np.full((3, h, w), 77, np.uint8)
+    noise = rng.integers(0, 256, (3, h, w), dtype=np.uint8)
+    chk = np.broadcast_to((((yy + xx) & 1) * 255).astype(np.uint8), (3, h, w)).copy()
+    bars = np.zeros((3, h, w), np.uint8)
+    bars[0] = np.where((xx // 3) % 2 == 0, 255, 0)
+    bars[2] = np.where((xx // 5) % 2 == 0, 0, 255)
+    return {"flat": flat, "noise": noise, "checkerboard": chk, "bars": bars}

@@ -139,3 +139,15 @@ def test_harness_reproduces_the_application_status_line(codec, tmp_path):
     assert harness.main(["decompress", out, back]) == 0
     from khugle_amd import read_bmp
     assert np.array_equal(read_bmp(back), harness.load_comp(out, codec)[0])
+
+
+@pytest.mark.parametrize("shape", [(72, 136), (512, 520)])
+@pytest.mark.parametrize("lvl", [0, 1, 2])
+def test_stress_pictures(codec, shape, lvl):
+    """Flat colour, white noise, checkerboard, extreme colour bars: bytes and pixels against the oracle."""
+    import craft
+    import oracle_py as O
+    for name, rgb in craft.stress_images(*shape).items():
+        comp = codec.encode(rgb, lvl)
+        assert comp == O.encode(rgb, lvl), name
+        assert np.array_equal(codec.decode(comp), O.decode(comp)), name

@@ -149,3 +149,15 @@ def test_ycbcr_plane_entry_points(shape, lvl):
     assert rc == 0
     _, (wy, wcb, wcr) = O.decode_planes(comp)
     assert np.array_equal(dy, wy) and np.array_equal(dcb, wcb) and np.array_equal(dcr, wcr)
+
+
+@pytest.mark.parametrize("lvl", [0, 2])
+def test_stress_pictures(lvl):
+    import craft
+    for name, rgb in craft.stress_images(72, 136).items():
+        rc, comp = S.encode(rgb, lvl)
+        assert rc == 0, name
+        assert comp == O.encode(rgb, lvl), name
+        rc, out, _, _ = S.decode(comp, 72, 136)
+        assert rc == 0, name
+        assert np.array_equal(out, O.decode(comp)), name
