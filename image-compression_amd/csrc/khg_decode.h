@@ -23,8 +23,16 @@
 #include "khg_common.h"
 #include "khg_huffman.h"
 
+// Bits per subsequence, a build-time choice (power of two, 128..512).  Measured on 8K frames: 256 shortens one
+// frame's decode (map 410 -> 265 us, write 155 -> 117 us: half as long serial chains per lane in the stretches
+// that need one run per residue class) but costs 5 % of batch throughput (twice the first-codeword work and
+// workgroup records); 512 is the better trade for the pipelined batch this library is benchmarked on.
+#ifndef KHG_SUB_BITS_CFG
+#define KHG_SUB_BITS_CFG 512
+#endif
+
 enum {
-    KHG_SUB_BITS = 512,       // bits per subsequence
+    KHG_SUB_BITS = KHG_SUB_BITS_CFG,  // bits per subsequence (a power of two >= 128; build-time choice)
     KHG_SUB_WORDS = KHG_SUB_BITS / 32,
     KHG_DEC_BLOCK = 256,      // subsequences per workgroup
     KHG_BLK_BITS = KHG_SUB_BITS * KHG_DEC_BLOCK,
