@@ -19,6 +19,7 @@
 #define KHG_SLOT tid
 #define KHG_BARRIER() ((void)0)
 #define KHG_UNROLL
+#define KHG_NOUNROLL
 static inline uint32_t khg_atomic_add(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o + v; return o; }
 static inline uint32_t khg_atomic_min(uint32_t* p, uint32_t v) { uint32_t o = *p; if (v < o) *p = v; return o; }
 static inline uint32_t khg_atomic_or(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o | v; return o; }
@@ -36,6 +37,7 @@ static inline void khg_atomic_max64(unsigned long long* p, unsigned long long v)
 #define KHG_SLOT 0
 #define KHG_BARRIER() __syncthreads()
 #define KHG_UNROLL _Pragma("unroll")
+#define KHG_NOUNROLL _Pragma("nounroll")
 __device__ __forceinline__ uint32_t khg_atomic_add(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
 __device__ __forceinline__ uint32_t khg_atomic_min(uint32_t* p, uint32_t v) { return atomicMin(p, v); }
 __device__ __forceinline__ uint32_t khg_atomic_or(uint32_t* p, uint32_t v) { return atomicOr(p, v); }

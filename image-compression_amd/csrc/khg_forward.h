@@ -317,6 +317,9 @@ KHG_DEV void khg_fwd_strip_body(const KhgFwdArgs& a, int bid, KhgFwdSmem<LEVEL>&
             const int xo = half ? hw + xq : xq;  // packed output column
             KhgLift st = cs[KHG_SLOT];
             KhgHot hot = hots[KHG_SLOT];
+            // kept as a loop: unrolled eight times, the rarely taken division paths of the quantiser alone made
+            // the kernel larger than the instruction cache likes
+            KHG_NOUNROLL
             for (int rr = 0; rr < KHG_BATCH; rr += 2) {
                 double en = sh.B[rr * KHG_B_PITCH + tid];
                 double on = sh.B[(rr + 1) * KHG_B_PITCH + tid];
