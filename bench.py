@@ -30,6 +30,10 @@ HBM_PEAK_GBS = 8000.0
 # + 2 (LL quadrant written as f64: 8 B on a quarter of the samples)
 # + 1.5 (int16 symbols of the three detail sub-bands: 2 B on three quarters)
 LUMA_FWD_BYTES_PER_PX = 6.5
+# the same launch priced by the pass-structured model (one kernel per stage, f64 planes between the stages): the luma
+# share of colour conversion (3 read + 8 written), DWT level 1 (8 + 8) and quantisation of the three detail
+# bands (three quarters of 8 read + 2 written)
+LUMA_FWD_STAGED_BYTES_PER_PX = 11 + 16 + 7.5
 
 
 def _cpu_worker(args):
@@ -300,6 +304,12 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "bytes_per_launch": LUMA_FWD_BYTES_PER_PX * px, "avg_launch_ms": round(k_ms, 4),
                          "launches_timed": k_launches,
+                         "staged_model": {
+                             "bytes_per_px": LUMA_FWD_STAGED_BYTES_PER_PX,
+                             "achieved": round(LUMA_FWD_STAGED_BYTES_PER_PX * px / (k_ms * 1e-3) / 1e9, 1),
+                             "frac": round(LUMA_FWD_STAGED_BYTES_PER_PX * px / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                             "note": "what the stages fused into this launch would move as separate passes; the "
+                                     "launch itself is priced above at its compulsory 6.5 B/px"},
                          "event_avg_launch_ms": round(k_event_ms, 4),
                          "note": "avg_launch_ms: execution span (first workgroup start to last workgroup end, device "
                                  "clock) of the launches inside the timed region, where the kernel shares the GPU "
