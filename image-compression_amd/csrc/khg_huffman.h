@@ -403,6 +403,7 @@ KHG_DEV void khg_lens_body(const KhgEncArgs& a, uint32_t chunk, KhgLensSmem& sh)
 
 struct KhgScanSmem {
     uint64_t psum[3][1024];
+    uint64_t grp[3][32];  // running totals of groups of 32 threads
     uint64_t base[3];     // bit offset of each plane's stream in the file
     uint64_t table_off;   // byte offset of the tables
     int ok;
@@ -425,8 +426,30 @@ KHG_DEV void khg_scan_body(const KhgEncArgs& a, KhgScanSmem& sh)
     {
         uint64_t s[3] = {0, 0, 0};
         uint32_t c0 = (uint32_t)tid * per, c1 = c0 + per < a.nchunks ? c0 + per : a.nchunks;
-        for (uint32_t c = c0; c < c1; ++c) s[khg_chunk_plane(a, c)] += a.chunk_bits[c];
+        for (uint32_t c = c0; c < c1; c += 8) {  // eight loads in flight at a time
+            uint32_t v[8];
+            KHG_UNROLL
+            for (int i = 0; i < 8; ++i) v[i] = c + i < c1 ? a.chunk_bits[c + i] : 0;
+            KHG_UNROLL
+            for (int i = 0; i < 8; ++i)
+                if (c + i < c1) s[khg_chunk_plane(a, c + i)] += v[i];
+        }
         for (int p = 0; p < 3; ++p) sh.psum[p][tid] = s[p];
+    }
+    KHG_BARRIER();
+    KHG_FOR_THREADS(1024)
+    {
+        // exclusive scan of the 1024 per-thread sums in two short serial steps: inside groups of 32 threads ...
+        if (tid < 96) {
+            const int p = tid >> 5, g = tid & 31;
+            uint64_t run = 0;
+            for (int i = 0; i < 32; ++i) {
+                uint64_t v = sh.psum[p][g * 32 + i];
+                sh.psum[p][g * 32 + i] = run;
+                run += v;
+            }
+            sh.grp[p][g] = run;
+        }
     }
     KHG_BARRIER();
     KHG_FOR_THREADS(1024)
@@ -436,10 +459,10 @@ KHG_DEV void khg_scan_body(const KhgEncArgs& a, KhgScanSmem& sh)
             uint64_t off = 36 * 8;
             int ok = res->status == 0;
             for (int p = 0; p < 3; ++p) {
-                uint64_t run = 0;
-                for (int t = 0; t < 1024; ++t) {
-                    uint64_t v = sh.psum[p][t];
-                    sh.psum[p][t] = run;
+                uint64_t run = 0;  // ... then over the 32 group totals
+                for (int g = 0; g < 32; ++g) {
+                    uint64_t v = sh.grp[p][g];
+                    sh.grp[p][g] = run;
                     run += v;
                 }
                 // Compress.h:310-328: pad with '0' to a multiple of 8 bits
@@ -490,16 +513,25 @@ KHG_DEV void khg_scan_body(const KhgEncArgs& a, KhgScanSmem& sh)
         if (sh.ok) {
             uint32_t* out32 = (uint32_t*)a.out;
             uint32_t c0 = (uint32_t)tid * per, c1 = c0 + per < a.nchunks ? c0 + per : a.nchunks;
-            uint64_t run[3] = {sh.psum[0][tid], sh.psum[1][tid], sh.psum[2][tid]};
-            for (uint32_t c = c0; c < c1; ++c) {
-                int p = khg_chunk_plane(a, c);
-                uint64_t off = sh.base[p] + run[p];
-                uint32_t bits = a.chunk_bits[c];
-                a.chunk_off[c] = off;
-                run[p] += bits;
-                if (bits) {  // words shared with neighbouring chunks are OR-merged by the packer: clear them
-                    out32[off >> 5] = 0;
-                    out32[(off + bits - 1) >> 5] = 0;
+            uint64_t run[3] = {sh.grp[0][tid >> 5] + sh.psum[0][tid], sh.grp[1][tid >> 5] + sh.psum[1][tid],
+                               sh.grp[2][tid >> 5] + sh.psum[2][tid]};
+            for (uint32_t cb = c0; cb < c1; cb += 8) {
+                uint32_t v[8];
+                KHG_UNROLL
+                for (int i = 0; i < 8; ++i) v[i] = cb + i < c1 ? a.chunk_bits[cb + i] : 0;
+                KHG_UNROLL
+                for (int i = 0; i < 8; ++i) {
+                    const uint32_t c = cb + i;
+                    if (c >= c1) break;
+                    int p = khg_chunk_plane(a, c);
+                    uint64_t off = sh.base[p] + run[p];
+                    uint32_t bits = v[i];
+                    a.chunk_off[c] = off;
+                    run[p] += bits;
+                    if (bits) {  // words shared with neighbouring chunks are OR-merged by the packer: clear them
+                        out32[off >> 5] = 0;
+                        out32[(off + bits - 1) >> 5] = 0;
+                    }
                 }
             }
             // the word holding the end of the streams also receives pad bits / the first table bytes
