@@ -361,6 +361,25 @@ KHG_DEV KhgChunk khg_chunk_info(const KhgEncArgs& a, uint32_t chunk)
     return c;
 }
 
+// Symbols [s0, s0 + 8) of a plane that lie below `end`: one 16-byte load when all eight do (the address is a
+// multiple of 8 bytes at least), element by element at the end of a run.  Returns how many are valid.
+KHG_DEV int khg_load8(const int16_t* sym, uint32_t s0, uint32_t end, int16_t v[8])
+{
+    if (s0 + 8 <= end) {
+        __builtin_memcpy(v, sym + s0, 16);
+        return 8;
+    }
+    int n = 0;
+    for (int i = 0; i < 8; ++i) {
+        v[i] = 0;
+        if (s0 + i < end) {
+            v[i] = sym[s0 + i];
+            n = i + 1;
+        }
+    }
+    return n;
+}
+
 struct KhgLensSmem {
     uint32_t part[256];
 };
@@ -376,9 +395,10 @@ KHG_DEV void khg_lens_body(const KhgEncArgs& a, uint32_t chunk, KhgLensSmem& sh)
     KHG_FOR_THREADS(256)
     {
         uint32_t s0 = base + (uint32_t)tid * 8, bits = 0;
-        const int16_t* q = a.sym[p] + s0;
+        int16_t v[8];
+        const int nv = khg_load8(a.sym[p], s0, end, v);
         for (int i = 0; i < 8; ++i)
-            if (s0 + i < end) bits += (uint32_t)(ctab[q[i] + KHG_SYM_BIAS] >> 56);
+            if (i < nv) bits += (uint32_t)(ctab[v[i] + KHG_SYM_BIAS] >> 56);
         sh.part[tid] = bits;
     }
     KHG_BARRIER();
@@ -589,9 +609,11 @@ KHG_DEV void khg_pack_body(const KhgEncArgs& a, uint32_t chunk, KhgPackSmem& sh)
     {
         for (uint32_t i = (uint32_t)tid; i < nw; i += 256) sh.words[i] = 0;
         uint32_t s0 = base + (uint32_t)tid * 8, tb = 0;
+        int16_t v[8];
+        const int nv = khg_load8(a.sym[p], s0, end, v);
         for (int i = 0; i < 8; ++i) {
             uint64_t c = 0;
-            if (s0 + i < end) c = ctab[a.sym[p][s0 + i] + KHG_SYM_BIAS];
+            if (i < nv) c = ctab[v[i] + KHG_SYM_BIAS];
             code[KHG_SLOT][i] = c;
             tb += (uint32_t)(c >> 56);
         }
