@@ -27,6 +27,7 @@ struct KhgFwdArgs {
     const uint8_t *r, *g, *b;  // full-resolution RGB planes, or a band of their rows
     int img_w;                 // their row pitch (image columns)
     int in_row0;               // image row held by the first row of r/g/b (0 for a whole image)
+    int in_rows;               // image rows r/g/b hold
     const double* src;         // KHG_SRC_PLANE: f64 source plane
     int src_pitch;
     int ph, pw;                // rows, cols of this transform
@@ -107,6 +108,15 @@ struct KhgFwdRaw {
 
 KHG_DEV uint32_t khg_ld32(const uint8_t* p) { return *(const uint32_t*)p; }
 
+// Image row `row` as a row of the r/g/b buffers.  The last batch of a segment runs past the rows its outputs need;
+// for a band of rows (a tile) those surplus rows may lie outside the band, so they are clamped into it -- their
+// results are discarded either way.
+KHG_DEV int khg_band_row(const KhgFwdArgs& a, int row)
+{
+    int r = row - a.in_row0;
+    return r < 0 ? 0 : (r >= a.in_rows ? a.in_rows - 1 : r);
+}
+
 // Row gy of the plane, samples gx0 .. gx0+23 (gx0 = 0 mod 4; columns outside [0, pw) are reflected).
 template <int SRC>
 KHG_DEV void khg_fwd_fetch(const KhgFwdArgs& a, KhgFwdRaw<SRC>& raw, int gy, int gx0)
@@ -118,8 +128,10 @@ KHG_DEV void khg_fwd_fetch(const KhgFwdArgs& a, KhgFwdRaw<SRC>& raw, int gy, int
             int gx = gx0 + 2 * k;
             double v0, v1;
             if (gx >= 0 && gx + 1 < a.pw) {  // pw is even: a pair is inside or outside as a whole
-                v0 = row[gx];
-                v1 = row[gx + 1];
+                double two[2];
+                __builtin_memcpy(two, row + gx, 16);  // one 16-byte load
+                v0 = two[0];
+                v1 = two[1];
             } else {
                 v0 = row[khg_reflect(gx, a.pw)];
                 v1 = row[khg_reflect(gx + 1, a.pw)];
@@ -128,7 +140,7 @@ KHG_DEV void khg_fwd_fetch(const KhgFwdArgs& a, KhgFwdRaw<SRC>& raw, int gy, int
             __builtin_memcpy(&raw.w[4 * k + 2], &v1, 8);
         }
     } else if (SRC == KHG_SRC_Y) {
-        const size_t rowoff = (size_t)(gy - a.in_row0) * a.img_w;
+        const size_t rowoff = (size_t)khg_band_row(a, gy) * a.img_w;
         KHG_UNROLL
         for (int k = 0; k < 6; ++k) {
             int gx = gx0 + 4 * k;
@@ -149,7 +161,7 @@ KHG_DEV void khg_fwd_fetch(const KhgFwdArgs& a, KhgFwdRaw<SRC>& raw, int gy, int
         }
     } else {
         // chroma site (gy, gx) reads the pixel at (2gy, 2gx): Colorspace.h:16-21
-        const size_t rowoff = (size_t)(2 * gy - a.in_row0) * a.img_w;
+        const size_t rowoff = (size_t)khg_band_row(a, 2 * gy) * a.img_w;
         KHG_UNROLL
         for (int k = 0; k < 6; ++k) {
             int gx = gx0 + 4 * k;

@@ -227,10 +227,15 @@ KHG_DEV void khg_inv_strip_body(const KhgInvArgs& a, int bid, KhgInvSmem& sh)
                 double cbv[8], crv[8], yv[16];
                 if (RGB) {  // issued first: in flight during the lifting below
                     const size_t cpos = (size_t)(gy >> 1) * (a.pw >> 1) + (gx0 >> 1);
-                    KHG_UNROLL
-                    for (int c = 0; c < 8; ++c) {
-                        cbv[c] = 2 * c < nv ? a.cb[cpos + c] : 0.0;
-                        crv[c] = 2 * c < nv ? a.cr[cpos + c] : 0.0;
+                    if (nv == 16) {  // 64 contiguous, 64-byte aligned bytes per plane: four 16-byte loads each
+                        __builtin_memcpy(cbv, a.cb + cpos, 64);
+                        __builtin_memcpy(crv, a.cr + cpos, 64);
+                    } else {
+                        KHG_UNROLL
+                        for (int c = 0; c < 8; ++c) {
+                            cbv[c] = 2 * c < nv ? a.cb[cpos + c] : 0.0;
+                            crv[c] = 2 * c < nv ? a.cr[cpos + c] : 0.0;
+                        }
                     }
                 }
                 KhgILift st = {0, 0, 0, 0};

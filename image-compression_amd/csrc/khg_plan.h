@@ -203,6 +203,7 @@ static inline KhgFwdArgs khg_fwd_args(const KhgWorkspace& ws, const uint8_t* r, 
     a.lvl = lvl;
     khg_make_quant(rows, cols, lvl, comp != 0, &a.q);
     a.in_row0 = khg_tile_in_row0(rows, tile);
+    a.in_rows = khg_tile_in_row1(rows, tile) - a.in_row0;
     const int R0 = khg_tile_row0(prow, tile), R1 = khg_tile_row1(prow, tile);  // the tile's band of this component
     if (level == 1) {
         a.row_begin = R0 - 8 < 0 ? 0 : R0 - 8;

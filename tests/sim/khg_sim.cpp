@@ -14,13 +14,17 @@
 #include "khg_dec_plan.h"
 #include "khg_synth.h"
 
+#ifndef KHG_SIM_SLACK
+#define KHG_SIM_SLACK 64  // bytes past each workspace array; 0 under AddressSanitizer to expose any overrun
+#endif
+
 namespace {
 
 struct SimWs {
     KhgWorkspace ws;
     std::vector<std::vector<char>> bufs;
     template <class T> T* alloc(size_t bytes) {
-        bufs.emplace_back(bytes + 64, 0);
+        bufs.emplace_back(bytes + KHG_SIM_SLACK, 0);
         return reinterpret_cast<T*>(bufs.back().data());
     }
     SimWs(int rows, int cols) {
