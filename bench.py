@@ -108,6 +108,7 @@ def main():
     ap.add_argument("--cols", type=int, default=COLS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-square", action="store_true", help="skip the short 5760x5760 pass")
+    ap.add_argument("--no-host-pipeline", action="store_true", help="skip the short pass over frames in host memory")
     ap.add_argument("--no-isolated-kernel", action="store_true",
                     help="skip timing the dominant kernel alone on an idle GPU (20 launches after the timed region)")
     ap.add_argument("--hw-queues", type=int, default=0,
@@ -257,6 +258,41 @@ def main():
                   "value": round(whole_job_rate(world, SF, 1, side * side, st), 1), "unit": "MP/s"}
         del sctx, sfr, scomp, sdec
 
+    # frames and files in (pinned) host memory through the library's pipelined batch entry points: the rate a host
+    # application sees, PCIe copies included.  Never part of `value`.
+    host = None
+    if not args.no_host_pipeline:
+        from khugle_amd.batch import Batch
+        HF, HD = 16, 8
+        hb = Batch(rows, cols, depth=HD, device=local_rank)
+        h_frames = torch.empty((HF, 3, rows, cols), dtype=torch.uint8).pin_memory()
+        h_frames.copy_(frames[:HF])
+        hcap = int(hb.L.khg_comp_bound(rows, cols))
+        h_comps = torch.empty((HF, hcap), dtype=torch.uint8).pin_memory()
+        h_dec = torch.empty((HF, 3, rows, cols), dtype=torch.uint8).pin_memory()
+        fp = [h_frames[i].data_ptr() for i in range(HF)]
+        cp = [h_comps[i].data_ptr() for i in range(HF)]
+        dp = [h_dec[i].data_ptr() for i in range(HF)]
+        hb.encode_ptrs(fp, rows, cols, LVL, cp, [hcap] * HF)  # warm-up
+        barrier()
+        ta = time.perf_counter()
+        rc_e, hl, _ = hb.encode_ptrs(fp, rows, cols, LVL, cp, [hcap] * HF)
+        tb = time.perf_counter()
+        rc_d, _ = hb.decode_ptrs(cp, hl, dp)
+        tc = time.perf_counter()
+        if rc_e or rc_d:
+            raise RuntimeError("host pipeline failed: %d %d" % (rc_e, rc_d))
+        if hl[0] != lens[0] or not torch.equal(h_comps[0, :hl[0]], comps[0, :lens[0]].cpu()):
+            raise RuntimeError("host pipeline bytes differ from the device-resident path")
+        he, hd_ = max_over_ranks([tb - ta, tc - tb], dev)
+        host = {"workload": "%d frames per GPU in pinned host memory, %d contexts in flight, one pass" % (HF, HD),
+                "value": round(whole_job_rate(world, HF, 1, px, he + hd_), 1), "unit": "MP/s",
+                "encode_mp_s": round(whole_job_rate(world, HF, 1, px, he), 1),
+                "decode_mp_s": round(whole_job_rate(world, HF, 1, px, hd_), 1),
+                "pcie_bytes_per_frame_each_way": 3 * px + int(sum(hl) / HF)}
+        hb.close()
+        del h_frames, h_comps, h_dec
+
     if rank == 0:
         # parity spot check (untimed): the last frame's bytes and pixels against the CPU oracle
         parity = None
@@ -328,6 +364,7 @@ def main():
                                "decode_gbps": round((63 + bpp / 8) * total_mp / t_dec / 1e3, 1),
                                "peak_gbps": HBM_PEAK_GBS * world},
             "square_variant": square,
+            "host_pipeline": host,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

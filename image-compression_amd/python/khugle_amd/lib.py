@@ -50,6 +50,10 @@ SYMBOLS = [
     ("khg_decode_ycbcr", C.c_int, [_P, _P, C.c_size_t, _P, _P, _P]),
     ("khg_encode_ycbcr_dev", C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_size_t, _P, _P, _P, _P]),
     ("khg_decode_ycbcr_dev", C.c_int, [_P, _P, C.c_size_t, C.c_int, C.c_int, _P, _P, _P, _P]),
+    ("khg_batch_create", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
+    ("khg_batch_destroy", None, [_P]),
+    ("khg_batch_encode", C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P]),
+    ("khg_batch_decode", C.c_int, [_P, C.c_int, _P, _P, _P, _P]),
     ("khg_tile_input_rows", C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("khg_tile_chunk_count", C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     ("khg_tile_forward_dev", C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),

@@ -120,6 +120,20 @@ int khg_symbols_dev(khg_ctx *ctx, const uint8_t *d_r, const uint8_t *d_g, const 
 int khg_time_luma_forward_dev(khg_ctx *ctx, const uint8_t *d_r, const uint8_t *d_g, const uint8_t *d_b, int rows,
                               int cols, int lvl, int reps, float *avg_ms, void *stream);
 
+/* ---- batches of frames in host memory: LoadBMPAndCompress / LoadComp (Main.cpp:180-334) called in a loop, as a
+ * pipeline.  `depth` contexts work on consecutive frames on streams of their own, so the PCIe copies of one frame
+ * overlap the kernels of others; buffers the caller has pinned (hipHostMalloc / hipHostRegister) are used in
+ * place, pageable ones go through pinned staging.  rgb[f] / rgb_out[f]: planar R, G, B of one frame; out[f] /
+ * comp[f]: one .comp file image.  status[f] receives each frame's khg_status; the return value is the first
+ * failure, KHG_OK if none. */
+typedef struct khg_batch khg_batch;
+int khg_batch_create(int device, int max_rows, int max_cols, int depth, khg_batch **out);
+void khg_batch_destroy(khg_batch *b);
+int khg_batch_encode(khg_batch *b, int n, const uint8_t *const *rgb, int rows, int cols, int lvl, uint8_t *const *out,
+                     const size_t *cap, size_t *out_len, int *status);
+int khg_batch_decode(khg_batch *b, int n, const uint8_t *const *comp, const size_t *len, uint8_t *const *rgb_out,
+                     int *status);
+
 /* ---- one image tiled by rows over several GPUs: one process and one context per GPU, rank t of n owns image
  * rows [rows*t/n, rows*(t+1)/n), rows a multiple of 8*n, n <= 8.  The reference has a single CompressImage call
  * (Compress.h:104) for this; the tiled form produces the same bytes.  The steps below do the per-GPU work; between
