@@ -2,21 +2,23 @@
 //
 // The format has no synchronisation markers (Writer.h:25-32 just concatenates codes), so the
 // first codeword of a chunk of the stream starts at an unknown offset.  Each plane's stream is
-// cut into 512-bit subsequences (one thread each, 256 per workgroup, staged in LDS).  The first
+// cut into subsequences of KHG_SUB_BITS bits (one thread each, 256 per workgroup, staged in LDS).  The first
 // codeword that starts inside a subsequence starts at one of its first M bits, M = the longest
 // code of the plane.  Instead of guessing, a thread works out, for EVERY start offset o < M,
 // where a decoder that starts there arrives in the next subsequence and how many codewords it
 // decodes on the way:
 //   map   : per subsequence, offset -> (arrival offset, count).  Offsets whose first codeword
 //           lands on another offset < M reuse that offset's entry; the others run on.  The first
-//           such run records the codeword starts it sees in a 512-bit map; every later run
+//           such run records the codeword starts it sees in a bit map; every later run
 //           stops as soon as it lands on one of them (Huffman codes self-synchronise, so this
 //           is normally within a few codewords; a fixed-length stretch costs one full run per
-//           residue instead).  The workgroup then composes its 256 maps into one.
+//           residue instead).  The workgroup then composes its 256 maps into one, one lane per
+//           start offset, and notes on the way where each subsequence is entered and how many
+//           codewords precede it (the walk table).
 //   chain : one thread per plane walks the workgroup maps from bit 0: exact start offset and
 //           output index of every workgroup.
-//   write : every workgroup walks its subsequence maps from its exact start, and every thread
-//           decodes its subsequence from its exact start and stores the symbols
+//   write : every thread reads its exact start and output index from the walk table column of
+//           its workgroup's start offset, decodes its subsequence and stores the symbols
 //           (Huffman.h:33-55: symbol i lands at raster index i).
 // Nothing is speculative: the result is exact for any code.
 #pragma once
