@@ -44,9 +44,12 @@ static int khg_decode_enqueue(khg_ctx* c, const uint8_t* d_comp, size_t len, int
     KHG_HIP(hipMemsetAsync(c->ws.res, 0, sizeof(KhgResult), st));
     hipLaunchKernelGGL(khg_dec_header_kernel, dim3(1), dim3(256), 0, st, d);
     hipLaunchKernelGGL(khg_dec_tree_kernel, dim3(3), dim3(256), 0, st, d);
-    hipLaunchKernelGGL(khg_dec_map_kernel, dim3(d.nblocks), dim3(256), 0, st, d);
+    // the three streams together are shorter than the file, and each ends inside one more workgroup at most
+    uint64_t spanned = (8ull * len) / KHG_BLK_BITS + 3;
+    const unsigned grid_dec = (unsigned)(spanned < d.nblocks ? spanned : d.nblocks);
+    hipLaunchKernelGGL(khg_dec_map_kernel, dim3(grid_dec), dim3(256), 0, st, d);
     hipLaunchKernelGGL(khg_dec_chain_kernel, dim3(3), dim3(256), 0, st, d);
-    hipLaunchKernelGGL(khg_dec_write_kernel, dim3(d.nblocks), dim3(256), 0, st, d);
+    hipLaunchKernelGGL(khg_dec_write_kernel, dim3(grid_dec), dim3(256), 0, st, d);
     KhgFwdGrid gr;
     for (int p = 0; p < 3; ++p) {  // Decompress.h:274-276
         KhgInvArgs a = khg_inv_args(c->ws, c->dws, rows, cols, p, 2, &gr, tile);

@@ -70,21 +70,27 @@ __global__ __launch_bounds__(256) void khg_dec_tree_kernel(KhgDecArgs a)
     khg_dec_tree_body(a, (int)blockIdx.x, sh);
 }
 
-// Workgroups are dispatched in blockIdx order and the slow ones sit at the start of each plane's stream
-// (the near-fixed-length codes of the LL band need one full run per residue).  Dispatching Cr, Cb, then Y
-// starts every slow workgroup in the first wave of dispatches instead of leaving the chroma ones for last.
+// Which workgroup of the decoder's capacity layout (KhgDecArgs::blk0) block b of a launch works on.  Only the
+// workgroups a stream really spans are launched (the host bounds their number by the file length), and they are
+// dispatched Cr, Cb, Y: workgroups run in blockIdx order and the slow ones sit at the start of each plane's stream
+// (the near-fixed-length codes of the LL band need one full run per residue), so this starts every slow
+// workgroup in the first wave of dispatches instead of leaving the chroma ones for last.  ~0u = nothing to do.
 __device__ __forceinline__ uint32_t khg_dec_dispatch_order(const KhgDecArgs& a, uint32_t b)
 {
-    const uint32_t c2 = a.nblocks - a.blk0[2], c1 = a.blk0[2] - a.blk0[1];
-    if (b < c2) return a.blk0[2] + b;
-    if (b < c2 + c1) return a.blk0[1] + (b - c2);
-    return b - c2 - c1;
+    if (!a.hdr->ok) return ~0u;
+    for (int p = 2; p >= 0; --p) {
+        const uint32_t nb = ((uint32_t)a.hdr->nbits[p] + KHG_BLK_BITS - 1) / KHG_BLK_BITS;
+        if (b < nb) return a.blk0[p] + b;
+        b -= nb;
+    }
+    return ~0u;
 }
 
 __global__ __launch_bounds__(256) void khg_dec_map_kernel(KhgDecArgs a)
 {
     __shared__ KhgDecSmem sh;
-    khg_dec_map_body(a, khg_dec_dispatch_order(a, blockIdx.x), sh);
+    const uint32_t blk = khg_dec_dispatch_order(a, blockIdx.x);
+    if (blk != ~0u) khg_dec_map_body(a, blk, sh);
 }
 
 __global__ __launch_bounds__(256) void khg_dec_chain_kernel(KhgDecArgs a)
@@ -96,7 +102,8 @@ __global__ __launch_bounds__(256) void khg_dec_chain_kernel(KhgDecArgs a)
 __global__ __launch_bounds__(256) void khg_dec_write_kernel(KhgDecArgs a)
 {
     __shared__ KhgDecWriteSmem sh;
-    khg_dec_write_body(a, khg_dec_dispatch_order(a, blockIdx.x), sh);
+    const uint32_t blk = khg_dec_dispatch_order(a, blockIdx.x);
+    if (blk != ~0u) khg_dec_write_body(a, blk, sh);
 }
 
 // 32 KB of LDS allows 5 workgroups per CU = 5 waves per SIMD; the bound keeps the register count (<= 96) from
