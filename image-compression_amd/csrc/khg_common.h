@@ -25,6 +25,8 @@ static inline uint32_t khg_atomic_min(uint32_t* p, uint32_t v) { uint32_t o = *p
 static inline uint32_t khg_atomic_or(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o | v; return o; }
 static inline int khg_atomic_max_i(int* p, int v) { int o = *p; if (v > o) *p = v; return o; }
 static inline void khg_lds_or(uint32_t* p, uint32_t v) { *p |= v; }
+static inline void khg_lds_add(uint32_t* p, uint32_t v) { *p += v; }
+static inline void khg_lds_min(uint32_t* p, uint32_t v) { if (v < *p) *p = v; }
 static inline uint32_t khg_bswap32(uint32_t v) { return __builtin_bswap32(v); }
 static inline double khg_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 static inline unsigned long long khg_clock(void) { return 0; }
@@ -43,6 +45,10 @@ __device__ __forceinline__ uint32_t khg_atomic_min(uint32_t* p, uint32_t v) { re
 __device__ __forceinline__ uint32_t khg_atomic_or(uint32_t* p, uint32_t v) { return atomicOr(p, v); }
 __device__ __forceinline__ int khg_atomic_max_i(int* p, int v) { return atomicMax(p, v); }
 __device__ __forceinline__ void khg_lds_or(uint32_t* p, uint32_t v) { atomicOr(p, v); }  // result unused: ds_or_b32, no wait
+// Workgroup-scope forms for LDS words: a different scope than the device-wide atomics above, so the compiler cannot
+// merge an LDS update and a global one into a single flat atomic behind a pointer select.
+__device__ __forceinline__ void khg_lds_add(uint32_t* p, uint32_t v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void khg_lds_min(uint32_t* p, uint32_t v) { __hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ uint32_t khg_bswap32(uint32_t v) { return __builtin_bswap32(v); }
 __device__ __forceinline__ double khg_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }  // explicit: not subject to -ffp-contract
 __device__ __forceinline__ unsigned long long khg_clock(void) { return (unsigned long long)wall_clock64(); }  // constant 100 MHz, chip-wide
@@ -95,13 +101,14 @@ KHG_DEV double khg_div_const(double x, double c, double rc)
 
 // round(c / div) of Compress.h:218 from rdiv = RN(1/div), when that is safe: t = c*rdiv is within 2^-51
 // (relative) of the exact quotient, so both round to the same integer unless t sits that close to a
-// half-integer.  Returns false (caller must divide) for anything within 2^-40 of one.
+// half-integer.  Returns false (caller must divide) for anything within 2^-31 of one -- which also covers every
+// |t| >= 2^30, NaN and infinity, so a true result always converts to int exactly.
 KHG_DEV bool khg_round_quot_fast(double c, double rdiv, double* n_out)
 {
     double t = c * rdiv;
-    double n = trunc(t + (t < 0 ? -0.5 : 0.5));
+    double n = __builtin_rint(t);  // ties aside (the caller divides for those), nearest-even == half-away
     *n_out = n;
-    return 0.5 - fabs(t - n) > fabs(t) * 0x1p-40;
+    return 0.5 - fabs(t - n) > fabs(t) * 0x1p-31;
 }
 
 // Whole-sample symmetric extension of index i onto [0, n), any i (n even, >= 2).
