@@ -262,13 +262,14 @@ KHG_DEV void khg_inv_strip_body(const KhgInvArgs& a, int bid, KhgInvSmem& sh)
                         for (int ch = 0; ch < 3; ++ch) pk[ch][c >> 2] |= (uint64_t)rgb[ch] << (16 * (c & 3));
                     }
                     const size_t p = (size_t)(gy - a.out_row0) * a.pw + gx0;
-                    *(uint64_t*)(a.r + p) = pk[0][0];
-                    *(uint64_t*)(a.g + p) = pk[1][0];
-                    *(uint64_t*)(a.b + p) = pk[2][0];
-                    if (nv == 16) {
-                        *(uint64_t*)(a.r + p + 8) = pk[0][1];
-                        *(uint64_t*)(a.g + p + 8) = pk[1][1];
-                        *(uint64_t*)(a.b + p + 8) = pk[2][1];
+                    if (nv == 16) {  // one 16-byte store per plane
+                        __builtin_memcpy(a.r + p, pk[0], 16);
+                        __builtin_memcpy(a.g + p, pk[1], 16);
+                        __builtin_memcpy(a.b + p, pk[2], 16);
+                    } else {
+                        __builtin_memcpy(a.r + p, pk[0], 8);
+                        __builtin_memcpy(a.g + p, pk[1], 8);
+                        __builtin_memcpy(a.b + p, pk[2], 8);
                     }
                 }
             }
