@@ -18,6 +18,7 @@
 #define KHG_FOR_THREADS(NT) for (int tid = 0; tid < (NT); ++tid)
 #define KHG_SLOT tid
 #define KHG_BARRIER() ((void)0)
+#define KHG_OPAQUE(x) ((void)0)
 #define KHG_UNROLL
 #define KHG_NOUNROLL
 static inline uint32_t khg_atomic_add(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o + v; return o; }
@@ -38,6 +39,9 @@ static inline void khg_atomic_max64(unsigned long long* p, unsigned long long v)
 #define KHG_FOR_THREADS(NT) for (int tid = (int)threadIdx.x, khg_once_ = 1; khg_once_; khg_once_ = 0)
 #define KHG_SLOT 0
 #define KHG_BARRIER() __syncthreads()
+// Makes a 32-bit value opaque to the optimiser at this point: what is computed from it afterwards cannot be hoisted
+// out of the (rarely taken) path it sits on into the common path, where it would only cost registers.
+#define KHG_OPAQUE(x) asm volatile("" : "+v"(x))
 #define KHG_UNROLL _Pragma("unroll")
 #define KHG_NOUNROLL _Pragma("nounroll")
 __device__ __forceinline__ uint32_t khg_atomic_add(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }

@@ -141,6 +141,7 @@ KHG_DEV void khg_fwd_fetch4_y(KhgFwdRaw<KHG_SRC_Y>& raw, int k, int gx, int pw, 
             r = khg_bswap32(khg_ld32u(pr + m)); g = khg_bswap32(khg_ld32u(pg + m)); b = khg_bswap32(khg_ld32u(pb + m));
         }
     } else {
+        KHG_OPAQUE(gx);
         for (int i = 0; i < 4; ++i) {
             int p = khg_reflect(gx + i, pw);
             r |= (uint32_t)pr[p] << (8 * i); g |= (uint32_t)pg[p] << (8 * i); b |= (uint32_t)pb[p] << (8 * i);
@@ -167,6 +168,7 @@ KHG_DEV void khg_fwd_fetch4_c(KhgFwdRaw<SRC>& raw, int k, int gx, int pw, const 
             b[0] = khg_rot16(khg_ld32u(pb + 2 * m - 2)); b[1] = khg_rot16(khg_ld32u(pb + 2 * m - 6));
         }
     } else {
+        KHG_OPAQUE(gx);
         for (int i = 0; i < 4; ++i) {
             int p = 2 * khg_reflect(gx + i, pw);
             r[i >> 1] |= (uint32_t)pr[p] << (16 * (i & 1));
@@ -193,6 +195,7 @@ KHG_DEV void khg_fwd_fetch2_p(KhgFwdRaw<KHG_SRC_PLANE>& raw, int k, int gx, int 
             v[0] = t[1]; v[1] = t[0];
         }
     } else {
+        KHG_OPAQUE(gx);
         v[0] = row[khg_reflect(gx, pw)];
         v[1] = row[khg_reflect(gx + 1, pw)];
     }
