@@ -19,6 +19,8 @@
 #define KHG_SLOT tid
 #define KHG_BARRIER() ((void)0)
 #define KHG_OPAQUE(x) ((void)0)
+#define KHG_TOUCH(reg, ptr) ((void)(reg), (void)(ptr))
+#define KHG_TOUCH_DONE(reg) ((void)(reg))
 #define KHG_UNROLL
 #define KHG_NOUNROLL
 static inline uint32_t khg_atomic_add(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o + v; return o; }
@@ -42,6 +44,11 @@ static inline void khg_atomic_max64(unsigned long long* p, unsigned long long v)
 // Makes a 32-bit value opaque to the optimiser at this point: what is computed from it afterwards cannot be hoisted
 // out of the (rarely taken) path it sits on into the common path, where it would only cost registers.
 #define KHG_OPAQUE(x) asm volatile("" : "+v"(x))
+// Cache warming: a 4-byte load whose result nobody waits for (gfx9 has no prefetch instruction).  `reg` is a 32-bit
+// variable that lives from before the first KHG_TOUCH to KHG_TOUCH_DONE, so the register the data eventually lands
+// in is never handed to anything else; KHG_TOUCH_DONE drains the memory counter before the variable dies.
+#define KHG_TOUCH(reg, ptr) asm volatile("global_load_dword %0, %1, off" : "+v"(reg) : "v"(ptr) : "memory")
+#define KHG_TOUCH_DONE(reg) asm volatile("s_waitcnt vmcnt(0)" : "+v"(reg) : : "memory")
 #define KHG_UNROLL _Pragma("unroll")
 #define KHG_NOUNROLL _Pragma("nounroll")
 __device__ __forceinline__ uint32_t khg_atomic_add(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }

@@ -154,6 +154,7 @@ KHG_DEV void khg_inv_strip_body(const KhgInvArgs& a, int bid, KhgInvSmem& sh)
     const bool PREFETCH = !RGB;
     KhgILift cs[KHG_NSLOT(256)];
     KhgInvRaw raws[KHG_NSLOT(256)];
+    uint32_t touch[KHG_NSLOT(256)] = {0};  // see KHG_TOUCH
     KHG_FOR_THREADS(256)
     {
         KhgILift z = {0, 0, 0, 0};
@@ -201,6 +202,24 @@ KHG_DEV void khg_inv_strip_body(const KhgInvArgs& a, int bid, KhgInvSmem& sh)
                     sh.T[(2 * s + 1) * KHG_T_PITCH + tid] = xod;
                 }
                 cs[KHG_SLOT] = st;
+                if (!PREFETCH && b + 1 < nb) {
+                    // No registers to hold the next batch in: at least bring its lines closer.  A wave's 64
+                    // columns span two 128-byte lines of a symbol row and five 64-byte pieces of an LL row; lane l
+                    // touches row slot l % 16 (symbols; first and last 16 lanes) or LL row l % 8 (every lane), each
+                    // at its own column.
+                    const int l = tid & 63;
+                    const int jn = k0 - 2 + (b + 1) * KHG_IBATCH;
+                    const bool llrows = khg_inv_band<LEVEL>(0, xo, hh, hw) < 0;  // low-pass rows come from the LL plane
+                    if (llrows) {
+                        const int ye = khg_reflect(2 * (jn + (l & 7)), a.ph) >> 1;
+                        KHG_TOUCH(touch[KHG_SLOT], a.ll + (size_t)ye * a.ll_pitch + xo);
+                    }
+                    if (l < 16 || l >= 48) {
+                        const int slot = l & 15, j = jn + (slot >> 1);
+                        const int row = (slot & 1) ? hh + (khg_reflect(2 * j + 1, a.ph) >> 1) : khg_reflect(2 * j, a.ph) >> 1;
+                        if ((slot & 1) || !llrows) KHG_TOUCH(touch[KHG_SLOT], a.sym + (size_t)row * a.sym_pitch + xo);
+                    }
+                }
                 if (PREFETCH && b + 1 < nb) {  // next batch's inputs: in flight during the row phase
                     KHG_UNROLL
                     for (int s = 0; s < KHG_IBATCH; ++s) {
@@ -275,6 +294,9 @@ KHG_DEV void khg_inv_strip_body(const KhgInvArgs& a, int bid, KhgInvSmem& sh)
             }
         }
         KHG_BARRIER();
+    }
+    if (!PREFETCH) {
+        KHG_FOR_THREADS(256) { KHG_TOUCH_DONE(touch[KHG_SLOT]); }
     }
 }
 
