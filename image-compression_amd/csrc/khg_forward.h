@@ -394,6 +394,7 @@ KHG_DEV void khg_fwd_strip_body(const KhgFwdArgs& a, int bid, KhgFwdSmem<LEVEL>&
     }
     KHG_BARRIER();
 
+    // developer build (-DKHG_PHASE_TIMING): core-clock time three workgroups spend per phase, printed at the end
 #if defined(KHG_PHASE_TIMING) && !defined(KHG_SIM)
     long long tacc[5] = {0, 0, 0, 0, 0}, tprev = clock64();
 #define KHG_PT(i) { long long t_ = clock64(); tacc[i] += t_ - tprev; tprev = t_; }
