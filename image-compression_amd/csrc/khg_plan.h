@@ -103,8 +103,10 @@ struct KhgFwdGrid {
     int nstrip, nseg, seg_rows;
 };
 // Splits ph rows into equal even-height segments for nstrip column strips.  Workgroups run in rounds of
-// `slots` (resident workgroups on the chip) and each costs its rows plus `halo` warm-up rows, so the
-// segment count is the one that minimises rounds x (rows + halo), with 32 <= rows <= max_rows.
+// `slots` (resident workgroups on the chip); a workgroup walks its rows plus `halo` warm-up rows in whole batches
+// of 16 rows (KHG_BATCH; 8 row pairs in the inverse transform), so the segment count is the one that minimises
+// rounds x batches -- the launch's critical path -- and, among those, the batches summed over all workgroups (the
+// work other launches cannot use), with 32 <= rows <= max_rows.
 static inline KhgFwdGrid khg_strip_grid(int ph, int nstrip, int slots, int halo, int max_rows)
 {
     KhgFwdGrid g;
@@ -112,15 +114,17 @@ static inline KhgFwdGrid khg_strip_grid(int ph, int nstrip, int slots, int halo,
     int lo = (ph + max_rows - 1) / max_rows, hi = ph / 32;
     if (lo < 1) lo = 1;
     if (hi < lo) hi = lo;
-    long best = -1;
+    long best = -1, best_work = -1;
     for (int n = lo; n <= hi; ++n) {
         int seg = ((ph + n - 1) / n + 1) & ~1;
         if (seg > max_rows) continue;
         int nseg = (ph + seg - 1) / seg;
         long rounds = ((long)nstrip * nseg + slots - 1) / slots;
-        long cost = rounds * (seg + halo);
-        if (best < 0 || cost < best) {
+        long batches = (seg + halo + 15) / 16;
+        long cost = rounds * batches, work = (long)nstrip * nseg * batches;
+        if (best < 0 || cost < best || (cost == best && work < best_work)) {
             best = cost;
+            best_work = work;
             g.seg_rows = seg;
             g.nseg = nseg;
         }
