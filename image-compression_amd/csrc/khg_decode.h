@@ -861,6 +861,30 @@ KHG_DEV void khg_dec_write_body(const KhgDecArgs& a, uint32_t blk, KhgDecWriteSm
         if (tid == 0) sh.pre[KHG_DEC_BLOCK] = a.blk[blk].map[entry] & 0xFFFFFFu;  // codewords of the whole workgroup
     }
     KHG_BARRIER();
+    // The workgroup's symbols are one contiguous stretch of the plane, and most of them are the plane's 1-bit
+    // symbol: the stretch is first filled with it in 16-byte stores by all threads (what a lane would otherwise
+    // write run by run, every lane of a wave into a different cache line), then each thread stores only the
+    // other symbols of its subsequence.
+    if (onebit >= 0) {
+        KHG_FOR_THREADS(256)
+        {
+            const uint32_t lim = a.n[p], o0 = a.blk[blk].out;
+            uint32_t o1 = o0 + sh.pre[KHG_DEC_BLOCK];
+            if (o1 > lim) o1 = lim;  // never store past the plane
+            if (o0 < o1) {
+                int16_t* base = a.sym[p];  // 16-byte aligned (workspace)
+                uint32_t a0 = (o0 + 7) & ~7u, a1 = o1 & ~7u;
+                if (a0 > o1) a0 = o1;
+                if (a1 < a0) a1 = a0;
+                const uint64_t z8[2] = {0x0001000100010001ull * (uint64_t)(uint16_t)(int16_t)onesym,
+                                        0x0001000100010001ull * (uint64_t)(uint16_t)(int16_t)onesym};
+                for (uint32_t i = o0 + (uint32_t)tid; i < a0; i += 256) base[i] = (int16_t)onesym;
+                for (uint32_t i = a0 + 8 * (uint32_t)tid; i < a1; i += 8 * 256) __builtin_memcpy(base + i, z8, 16);
+                for (uint32_t i = a1 + (uint32_t)tid; i < o1; i += 256) base[i] = (int16_t)onesym;
+            }
+        }
+        KHG_BARRIER();  // the fill is complete (and visible to this workgroup) before single symbols land in it
+    }
     KHG_FOR_THREADS(256)
     {
         const uint32_t off = offs[KHG_SLOT], cnt = sh.pre[tid + 1] - sh.pre[tid];
@@ -872,22 +896,13 @@ KHG_DEV void khg_dec_write_body(const KhgDecArgs& a, uint32_t blk, KhgDecWriteSm
             int16_t* q = a.sym[p] + o;
             KhgCursor cur;
             khg_cur_init(cur, bits, pos);
-            const uint64_t z4 = 0x0001000100010001ull * (uint64_t)(uint16_t)(int16_t)onesym;
-            // Each trip takes a run of the 1-bit code (possibly empty) and then one other codeword, so the
-            // lanes of a wave stay in step through "zeros, then a value".  A run goes out as up to eight
-            // 8-byte stores plus a 4- and a 2-byte one, all straight-line; the stores are only 2-byte
-            // aligned, which global memory accepts.
+            // Each trip steps over a run of the 1-bit code (possibly empty; already filled in) and then takes one
+            // other codeword, so the lanes of a wave stay in step through "zeros, then a value".
             uint32_t i = 0;
             while (i < todo) {
                 const uint32_t r = khg_cur_runlen(cur, onebit, todo - i);  // 0..32
                 if (r) {
                     khg_cur_skip(cur, bits, r);
-                    int16_t* d = q + i;
-                    KHG_UNROLL
-                    for (uint32_t k4 = 0; k4 < 8; ++k4)
-                        if (4 * k4 + 4 <= r) __builtin_memcpy(d + 4 * k4, &z4, 8);
-                    if (r & 2) __builtin_memcpy(d + (r & ~3u), &z4, 4);
-                    if (r & 1) d[r - 1] = (int16_t)onesym;
                     i += r;
                 }
                 if (i < todo && r < 32) {  // a run cut at 32 may simply go on
