@@ -380,8 +380,13 @@ KHG_DEV int khg_load8(const int16_t* sym, uint32_t s0, uint32_t end, int16_t v[8
     return n;
 }
 
+// Code table entries of the symbols -128 .. 127 (nearly every symbol) are fetched once per workgroup, coalesced,
+// into LDS; the others are gathered from the global table.
+enum { KHG_HOT_SYMS = 256 };
+
 struct KhgLensSmem {
     uint32_t part[256];
+    uint8_t len8[KHG_HOT_SYMS];
 };
 
 // One chunk per workgroup, 8 symbols per thread.
@@ -392,13 +397,25 @@ KHG_DEV void khg_lens_body(const KhgEncArgs& a, uint32_t chunk, KhgLensSmem& sh)
     const int p = ck.plane;
     const uint64_t* ctab = a.codetab + (size_t)p * KHG_NBINS;
     const uint32_t base = ck.sym0, end = ck.sym0 + ck.nsym;
+    int16_t vs[KHG_NSLOT(256)][8];
+    int nvs[KHG_NSLOT(256)];
     KHG_FOR_THREADS(256)
     {
-        uint32_t s0 = base + (uint32_t)tid * 8, bits = 0;
-        int16_t v[8];
-        const int nv = khg_load8(a.sym[p], s0, end, v);
-        for (int i = 0; i < 8; ++i)
-            if (i < nv) bits += (uint32_t)(ctab[v[i] + KHG_SYM_BIAS] >> 56);
+        sh.len8[tid] = (uint8_t)(ctab[KHG_SYM_BIAS - KHG_HOT_SYMS / 2 + tid] >> 56);
+        nvs[KHG_SLOT] = khg_load8(a.sym[p], base + (uint32_t)tid * 8, end, vs[KHG_SLOT]);
+    }
+    KHG_BARRIER();
+    KHG_FOR_THREADS(256)
+    {
+        uint32_t bits = 0;
+        const int16_t* v = vs[KHG_SLOT];
+        const int nv = nvs[KHG_SLOT];
+        for (int i = 0; i < 8; ++i) {
+            if (i < nv) {
+                const uint32_t h = (uint32_t)(v[i] + KHG_HOT_SYMS / 2);
+                bits += h < (uint32_t)KHG_HOT_SYMS ? sh.len8[h] : (uint32_t)(ctab[v[i] + KHG_SYM_BIAS] >> 56);
+            }
+        }
         sh.part[tid] = bits;
     }
     KHG_BARRIER();
@@ -585,6 +602,7 @@ struct KhgPackSmem {
     uint32_t words[KHG_PACK_WORDS];
     uint32_t part[256];
     uint32_t grp[16];
+    uint64_t hot[KHG_HOT_SYMS];  // see KHG_HOT_SYMS
 };
 
 // One chunk per workgroup, 8 symbols per thread.  The chunk's bits are assembled in LDS in
@@ -605,15 +623,26 @@ KHG_DEV void khg_pack_body(const KhgEncArgs& a, uint32_t chunk, KhgPackSmem& sh)
     const uint32_t nw = (lead + bits + 31) >> 5;
 
     uint64_t code[KHG_NSLOT(256)][8];
+    int16_t vs[KHG_NSLOT(256)][8];
+    int nvs[KHG_NSLOT(256)];
     KHG_FOR_THREADS(256)
     {
+        sh.hot[tid] = ctab[KHG_SYM_BIAS - KHG_HOT_SYMS / 2 + tid];
         for (uint32_t i = (uint32_t)tid; i < nw; i += 256) sh.words[i] = 0;
-        uint32_t s0 = base + (uint32_t)tid * 8, tb = 0;
-        int16_t v[8];
-        const int nv = khg_load8(a.sym[p], s0, end, v);
+        nvs[KHG_SLOT] = khg_load8(a.sym[p], base + (uint32_t)tid * 8, end, vs[KHG_SLOT]);
+    }
+    KHG_BARRIER();
+    KHG_FOR_THREADS(256)
+    {
+        uint32_t tb = 0;
+        const int16_t* v = vs[KHG_SLOT];
+        const int nv = nvs[KHG_SLOT];
         for (int i = 0; i < 8; ++i) {
             uint64_t c = 0;
-            if (i < nv) c = ctab[v[i] + KHG_SYM_BIAS];
+            if (i < nv) {
+                const uint32_t h = (uint32_t)(v[i] + KHG_HOT_SYMS / 2);
+                c = h < (uint32_t)KHG_HOT_SYMS ? sh.hot[h] : ctab[v[i] + KHG_SYM_BIAS];
+            }
             code[KHG_SLOT][i] = c;
             tb += (uint32_t)(c >> 56);
         }
