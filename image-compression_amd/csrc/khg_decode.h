@@ -45,7 +45,6 @@ enum {
     KHG_LUT2_BITS = 8,        // second-level tables: the next 8 bits after a first-level miss
     KHG_LUT2_SIZE = 1 << KHG_LUT2_BITS,
     KHG_MAXOFF = KHG_MAX_CODE_BITS,  // start offsets 0..55
-    KHG_RUN_ILP = 4,          // rejoining runs a thread advances side by side (khg_dec_map_body)
     KHG_OFF_TEMP = 62,        // map entry not final yet: the count field holds the landing offset
     KHG_OFF_NONE = 63         // no codeword starts from here on (the stream has ended)
 };
@@ -611,107 +610,73 @@ KHG_DEV void khg_dec_map_body(const KhgDecArgs& a, uint32_t blk, KhgDecSmem& sh)
         if (tid == 0) a.blk[blk].pad_[4] = (uint32_t)wall_clock64();
 #endif
         //    Every other such run stops as soon as it lands on a recorded start (inside a run of the 1-bit
-        //    code every position is one, so no run handling is needed here).  Runs that do not rejoin --
-        //    a stretch of near-equal code lengths has one per residue -- are long chains of dependent LDS
-        //    lookups, so KHG_RUN_ILP of them advance together, one codeword each per trip, with the
-        //    lookups of all of them issued before any is used.
+        //    code every position is one, so no run handling is needed here).  Most rejoin within a few
+        //    codewords; a stretch of near-equal code lengths has one run per residue class that never does.
+        //    No bit window is carried from step to step: a step reads the two stream words under its position
+        //    afresh, which is fewer instructions than keeping a window topped up.  (Advancing several runs side
+        //    by side to overlap their LDS round trips was slower: the lanes of a wave then wait for the longest
+        //    of all of them.)
         while (have_main) {
-            uint32_t ro[KHG_RUN_ILP], rpos[KHG_RUN_ILP], rn[KHG_RUN_ILP], rjoin[KHG_RUN_ILP];
-            bool ract[KHG_RUN_ILP], rused[KHG_RUN_ILP], rdead[KHG_RUN_ILP];
-            KhgCursor rc[KHG_RUN_ILP];
-            KHG_UNROLL
-            for (int k = 0; k < KHG_RUN_ILP; ++k) {
-                rused[k] = false;
-                ro[k] = 0;
-                rpos[k] = sub_begin;
-                while (oo > 0) {
-                    --oo;
-                    const uint16_t e0 = map[oo * KHG_DEC_BLOCK];
-                    if (khg_map_arr(e0) == KHG_OFF_TEMP && khg_map_cnt(e0) >= M) {
-                        rused[k] = true;
-                        ro[k] = (uint32_t)oo;
-                        rpos[k] = sub_begin + khg_map_cnt(e0);
-                        break;
-                    }
+            bool found = false;
+            uint32_t ro = 0, rpos = sub_begin;
+            while (oo > 0) {
+                --oo;
+                const uint16_t e0 = map[oo * KHG_DEC_BLOCK];
+                if (khg_map_arr(e0) == KHG_OFF_TEMP && khg_map_cnt(e0) >= M) {
+                    found = true;
+                    ro = (uint32_t)oo;
+                    rpos = sub_begin + khg_map_cnt(e0);
+                    break;
                 }
-                rn[k] = 1;
-                rjoin[k] = 0xFFFFFFFFu;
-                rdead[k] = false;
-                ract[k] = rused[k] && rpos[k] < end;
-                khg_cur_init(rc[k], bits, ract[k] ? rpos[k] : sub_begin);
             }
-            if (!rused[0]) break;
-            bool any = false;
-            KHG_UNROLL
-            for (int k = 0; k < KHG_RUN_ILP; ++k) any = any || ract[k];
-            while (any) {
-                uint32_t mw[KHG_RUN_ILP], le[KHG_RUN_ILP], nx[KHG_RUN_ILP], relc[KHG_RUN_ILP];
-                KHG_UNROLL
-                for (int k = 0; k < KHG_RUN_ILP; ++k) {  // all lookups first (a finished run repeats its last ones)
-                    const uint32_t rel = rpos[k] - sub_begin;
-                    relc[k] = rel < KHG_SUB_BITS ? rel : KHG_SUB_BITS - 1;
-                    mw[k] = mask[(relc[k] >> 5) * KHG_DEC_BLOCK];
-                    le[k] = sh.lut[(uint32_t)(rc[k].buf >> (64 - KHG_LUT_BITS))];
-                    nx[k] = bits.stage[khg_stage_slot(rc[k].next)];
-                }
-                any = false;
-                KHG_UNROLL
-                for (int k = 0; k < KHG_RUN_ILP; ++k) {
-                    if (!ract[k]) continue;
-                    const uint32_t len = (le[k] >> 16) & 0xFF;
-                    if ((mw[k] << (relc[k] & 31)) & 0x80000000u) {  // a codeword start of the first run: identical from here on
-                        rjoin[k] = relc[k];
-                        ract[k] = false;
-                    } else if (!(le[k] & 0x80000000u)) {  // longer than the first-level table: the general decoder
-                        int s;
-                        const uint32_t l2 = khg_decode_one(bits, sh.lut, lut2, left, right, tsym, rpos[k], &s);
-                        if (l2 == 0) {
-                            rdead[k] = true;
-                            ract[k] = false;
-                        } else {
-                            rpos[k] += l2;
-                            ++rn[k];
-                            ract[k] = rpos[k] < end;
-                            khg_cur_init(rc[k], bits, ract[k] ? rpos[k] : sub_begin);
-                        }
-                    } else if (rpos[k] + len > nbits) {  // the stream ends inside this codeword
-                        rdead[k] = true;
-                        ract[k] = false;
+            if (!found) break;
+            uint32_t rn = 1, rjoin = 0xFFFFFFFFu;
+            bool rdead = false, ract = rpos < end;
+            while (ract) {  // one exit, at the bottom: the lanes of a wave stay in one loop
+                const uint32_t rel = rpos - sub_begin;  // < KHG_SUB_BITS
+                const uint32_t mw = mask[(rel >> 5) * KHG_DEC_BLOCK];
+                const uint32_t w = (rpos - bits.bias) >> 5;
+                const uint32_t wa = bits.stage[khg_stage_slot(w)], wb = bits.stage[khg_stage_slot(w + 1)];
+                const uint32_t win = (uint32_t)(((((uint64_t)wa << 32) | wb) << ((rpos - bits.bias) & 31)) >> 32);
+                const uint32_t le = sh.lut[win >> (32 - KHG_LUT_BITS)];
+                const uint32_t len = (le >> 16) & 0xFF;
+                if ((mw << (rel & 31)) & 0x80000000u) {  // a codeword start of the first run: identical from here on
+                    rjoin = rel;
+                    ract = false;
+                } else if (!(le & 0x80000000u)) {  // longer than the first-level table: the general decoder
+                    int s;
+                    const uint32_t l2 = khg_decode_one(bits, sh.lut, lut2, left, right, tsym, rpos, &s);
+                    if (l2 == 0) {
+                        rdead = true;
+                        ract = false;
                     } else {
-                        KhgCursor& c = rc[k];
-                        c.buf <<= len;
-                        c.avail -= (int)len;
-                        c.pos += len;
-                        if (c.avail <= 32) {
-                            c.buf |= (uint64_t)nx[k] << (32 - c.avail);
-                            c.avail += 32;
-                            c.next++;
-                        }
-                        rpos[k] += len;
-                        ++rn[k];
-                        ract[k] = rpos[k] < end;
+                        rpos += l2;
+                        ++rn;
+                        ract = rpos < end;
                     }
-                    any = any || ract[k];
-                }
-            }
-            KHG_UNROLL
-            for (int k = 0; k < KHG_RUN_ILP; ++k) {
-                if (!rused[k]) continue;
-                uint32_t arr, n = rn[k];
-                if (rjoin[k] != 0xFFFFFFFFu) {
-                    const uint32_t wq = rjoin[k] >> 5, bit = 0x80000000u >> (rjoin[k] & 31);
-                    uint32_t rest = (uint32_t)__builtin_popcount(mask[wq * KHG_DEC_BLOCK] & (bit | (bit - 1)));
-                    for (uint32_t w2 = wq + 1; w2 < KHG_SUB_WORDS; ++w2)
-                        rest += (uint32_t)__builtin_popcount(mask[w2 * KHG_DEC_BLOCK]);
-                    n += rest;
-                    arr = main_arr;
-                } else if (rdead[k] || rpos[k] >= nbits) {
-                    arr = KHG_OFF_NONE;
+                } else if (rpos + len > nbits) {  // the stream ends inside this codeword
+                    rdead = true;
+                    ract = false;
                 } else {
-                    arr = rpos[k] - (sub_begin + KHG_SUB_BITS);
+                    rpos += len;
+                    ++rn;
+                    ract = rpos < end;
                 }
-                map[ro[k] * KHG_DEC_BLOCK] = khg_map_entry(arr, n);
             }
+            uint32_t arr, n = rn;
+            if (rjoin != 0xFFFFFFFFu) {
+                const uint32_t wq = rjoin >> 5, bit = 0x80000000u >> (rjoin & 31);
+                uint32_t rest = (uint32_t)__builtin_popcount(mask[wq * KHG_DEC_BLOCK] & (bit | (bit - 1)));
+                for (uint32_t w2 = wq + 1; w2 < KHG_SUB_WORDS; ++w2)
+                    rest += (uint32_t)__builtin_popcount(mask[w2 * KHG_DEC_BLOCK]);
+                n += rest;
+                arr = main_arr;
+            } else if (rdead || rpos >= nbits) {
+                arr = KHG_OFF_NONE;
+            } else {
+                arr = rpos - (sub_begin + KHG_SUB_BITS);
+            }
+            map[ro * KHG_DEC_BLOCK] = khg_map_entry(arr, n);
         }
         // 3. the other offsets reuse the entry of the offset their first codeword lands on
         for (uint32_t oo = M; oo-- > 0;) {
