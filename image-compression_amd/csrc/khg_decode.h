@@ -864,17 +864,23 @@ KHG_DEV void khg_dec_write_body(const KhgDecArgs& a, uint32_t blk, KhgDecWriteSm
             // Each trip steps over a run of the 1-bit code (possibly empty; already filled in) and then takes one
             // other codeword, so the lanes of a wave stay in step through "zeros, then a value".
             uint32_t i = 0;
-            while (i < todo) {
+            bool go = todo != 0;
+            while (go) {  // one exit, at the bottom
                 const uint32_t r = khg_cur_runlen(cur, onebit, todo - i);  // 0..32
                 if (r) {
                     khg_cur_skip(cur, bits, r);
                     i += r;
                 }
-                if (i < todo && r < 32) {  // a run cut at 32 may simply go on
+                go = i < todo;
+                if (go && r < 32) {  // a run cut at 32 may simply go on
                     int s;
-                    if (khg_cur_decode(cur, bits, sh.lut, lut2, left, right, tsym, &s) == 0) break;
-                    q[i] = (int16_t)s;
-                    ++i;
+                    if (khg_cur_decode(cur, bits, sh.lut, lut2, left, right, tsym, &s) == 0) {
+                        go = false;  // the stream broke off
+                    } else {
+                        q[i] = (int16_t)s;
+                        ++i;
+                        go = i < todo;
+                    }
                 }
             }
         }
