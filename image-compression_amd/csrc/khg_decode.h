@@ -459,6 +459,42 @@ KHG_DEV uint32_t khg_cur_decode(KhgCursor& c, const KhgBitsL& b, const uint32_t*
     return len;
 }
 
+// The map kernel only needs code lengths.  len8[v] = length of the code that the KHG_LUT_BITS-bit prefix v starts
+// with, 0 if it is longer than that (then the general decoder, with the tables in global memory, finds it).
+KHG_DEV uint32_t khg_len_at(const KhgBitsL& b, const uint8_t* len8, const uint32_t* glut, const uint32_t* lut2,
+                            const int32_t* left, const int32_t* right, const int32_t* tsym, uint32_t pos)
+{
+    uint32_t len = len8[b.peek32(pos) >> (32 - KHG_LUT_BITS)];
+    if (len == 0) {
+        int s;
+        return khg_decode_one(b, glut, lut2, left, right, tsym, pos, &s);
+    }
+    return pos + len > b.nbits ? 0 : len;
+}
+
+// khg_cur_decode without the symbol.
+KHG_DEV uint32_t khg_cur_step(KhgCursor& c, const KhgBitsL& b, const uint8_t* len8, const uint32_t* glut,
+                              const uint32_t* lut2, const int32_t* left, const int32_t* right, const int32_t* tsym)
+{
+    const uint32_t len = len8[(uint32_t)(c.buf >> (64 - KHG_LUT_BITS))];
+    if (len == 0) {  // longer than the first-level table: general decoder, then re-seat the window
+        int s;
+        const uint32_t l2 = khg_decode_one(b, glut, lut2, left, right, tsym, c.pos, &s);
+        if (l2) khg_cur_init(c, b, c.pos + l2);
+        return l2;
+    }
+    if (c.pos + len > b.nbits) return 0;
+    c.buf <<= len;
+    c.avail -= (int)len;
+    c.pos += len;
+    if (c.avail <= 32) {
+        c.buf |= (uint64_t)b.stage[khg_stage_slot(c.next)] << (32 - c.avail);
+        c.avail += 32;
+        c.next++;
+    }
+    return len;
+}
+
 // Length (at most 32 and at most lim) of the run of 1-bit codewords `onebit` at the cursor; 0 if none.
 KHG_DEV uint32_t khg_cur_runlen(const KhgCursor& c, int onebit, uint32_t lim)
 {
@@ -490,12 +526,16 @@ KHG_DEV uint64_t khg_mask_range(uint32_t rel, uint32_t r)
     return ones << (64 - b - r);
 }
 
+// LDS of the map kernel.  MO = start offsets it has room for: with 32 (codes up to 32 bits, i.e. nearly every
+// stream) a workgroup needs 52.6 KB and three fit on a CU; streams with longer codes are handled by the
+// KHG_MAXOFF instantiation (two per CU).  A launch of either does nothing for planes that belong to the other.
+enum { KHG_MAP_SMALL = 32 };
+template <int MO>
 struct KhgDecSmem {
-    uint32_t lut[KHG_LUT_SIZE];
+    uint8_t len8[KHG_LUT_SIZE];                    // see khg_len_at
     uint32_t stage[KHG_STAGE_LDS];
     uint32_t mask[KHG_SUB_WORDS * KHG_DEC_BLOCK];  // word-major: thread t's word w at [w * 256 + t]
-    uint16_t map[KHG_MAXOFF * KHG_DEC_BLOCK];      // offset-major: thread t's entry for offset o at [o * 256 + t]
-    uint32_t grp[16];
+    uint16_t map[MO * KHG_DEC_BLOCK];              // offset-major: thread t's entry for offset o at [o * 256 + t]
 };
 
 // Stage the LUT and the workgroup's span of the stream (byte-swapped words) in LDS.
@@ -522,8 +562,36 @@ KHG_DEV KhgBitsL khg_dec_stage(const KhgDecArgs& a, int p, uint32_t blk_begin, S
     return l;
 }
 
+// The map kernel's staging: code lengths instead of the decode table, and the workgroup's span of the stream.
+template <class SMEM>
+KHG_DEV KhgBitsL khg_dec_stage_lens(const KhgDecArgs& a, int p, uint32_t blk_begin, SMEM& sh)
+{
+    const uint32_t* words = (const uint32_t*)a.comp;
+    const uint32_t nwords = (uint32_t)(a.len >> 2);
+    const uint32_t* glut = a.lut + (size_t)p * KHG_LUT_SIZE;
+    const uint64_t gbit = 8ull * a.hdr->stream_byte[p] + blk_begin;
+    const uint32_t w0 = (uint32_t)(gbit >> 5);
+    KHG_FOR_THREADS(256)
+    {
+        for (int i = tid; i < KHG_LUT_SIZE; i += 256) {
+            const uint32_t e = glut[i];
+            sh.len8[i] = (e & 0x80000000u) ? (uint8_t)((e >> 16) & 0xFF) : (uint8_t)0;
+        }
+        for (uint32_t i = (uint32_t)tid; i < KHG_STAGE_WORDS; i += 256) {
+            uint32_t w = w0 + i;
+            sh.stage[khg_stage_slot(i)] = w < nwords ? khg_bswap32(words[w]) : 0;
+        }
+    }
+    KhgBitsL l;
+    l.stage = sh.stage;
+    l.bias = blk_begin - (uint32_t)(gbit & 31);
+    l.nbits = (uint32_t)a.hdr->nbits[p];
+    return l;
+}
+
 // One workgroup = 256 consecutive subsequences of one plane: subsequence maps and their composition.
-KHG_DEV void khg_dec_map_body(const KhgDecArgs& a, uint32_t blk, KhgDecSmem& sh)
+template <int MO>
+KHG_DEV void khg_dec_map_body(const KhgDecArgs& a, uint32_t blk, KhgDecSmem<MO>& sh)
 {
     if (!a.hdr->ok) return;
     const int p = khg_block_plane(a, blk);
@@ -533,6 +601,8 @@ KHG_DEV void khg_dec_map_body(const KhgDecArgs& a, uint32_t blk, KhgDecSmem& sh)
     if (blk_begin >= nbits) return;
     const uint32_t M = (uint32_t)a.hdr->maxlen[p];
     if (M == 0 || M > KHG_MAXOFF) return;  // flagged by the tree kernel
+    if ((M <= KHG_MAP_SMALL) != (MO == KHG_MAP_SMALL)) return;  // the other instantiation's plane
+    const uint32_t* glut = a.lut + (size_t)p * KHG_LUT_SIZE;
     const int32_t* left = a.tree_left + (size_t)p * 2 * KHG_NBINS;
     const int32_t* right = a.tree_right + (size_t)p * 2 * KHG_NBINS;
     const int32_t* tsym = a.tab_sym + (size_t)p * KHG_NBINS;
@@ -541,7 +611,7 @@ KHG_DEV void khg_dec_map_body(const KhgDecArgs& a, uint32_t blk, KhgDecSmem& sh)
 #ifdef KHG_TIMING
     const long long tmap0 = wall_clock64();
 #endif
-    const KhgBitsL bits = khg_dec_stage(a, p, blk_begin, sh);
+    const KhgBitsL bits = khg_dec_stage_lens(a, p, blk_begin, sh);
     KHG_BARRIER();
 
     KHG_FOR_THREADS(256)
@@ -555,8 +625,7 @@ KHG_DEV void khg_dec_map_body(const KhgDecArgs& a, uint32_t blk, KhgDecSmem& sh)
             uint32_t pos = sub_begin + o;
             uint16_t e = khg_map_entry(KHG_OFF_NONE, 0);
             if (pos < end) {
-                int s;
-                uint32_t len = khg_decode_one(bits, sh.lut, lut2, left, right, tsym, pos, &s);
+                uint32_t len = khg_len_at(bits, sh.len8, glut, lut2, left, right, tsym, pos);
                 if (len) e = khg_map_entry(KHG_OFF_TEMP, o + len);  // landing offset < 2 * 56
             }
             map[o * KHG_DEC_BLOCK] = e;
@@ -589,8 +658,7 @@ KHG_DEV void khg_dec_map_body(const KhgDecArgs& a, uint32_t blk, KhgDecSmem& sh)
                     rel += r;
                 }
                 if (pos < end && r < 32) {  // a run cut at 32 may simply go on
-                    int s;
-                    uint32_t len = khg_cur_decode(cur, bits, sh.lut, lut2, left, right, tsym, &s);
+                    uint32_t len = khg_cur_step(cur, bits, sh.len8, glut, lut2, left, right, tsym);
                     if (len == 0) {
                         dead = true;
                         break;
@@ -638,14 +706,13 @@ KHG_DEV void khg_dec_map_body(const KhgDecArgs& a, uint32_t blk, KhgDecSmem& sh)
                 const uint32_t w = (rpos - bits.bias) >> 5;
                 const uint32_t wa = bits.stage[khg_stage_slot(w)], wb = bits.stage[khg_stage_slot(w + 1)];
                 const uint32_t win = (uint32_t)(((((uint64_t)wa << 32) | wb) << ((rpos - bits.bias) & 31)) >> 32);
-                const uint32_t le = sh.lut[win >> (32 - KHG_LUT_BITS)];
-                const uint32_t len = (le >> 16) & 0xFF;
+                const uint32_t len = sh.len8[win >> (32 - KHG_LUT_BITS)];
                 if ((mw << (rel & 31)) & 0x80000000u) {  // a codeword start of the first run: identical from here on
                     rjoin = rel;
                     ract = false;
-                } else if (!(le & 0x80000000u)) {  // longer than the first-level table: the general decoder
+                } else if (len == 0) {  // longer than the first-level table: the general decoder
                     int s;
-                    const uint32_t l2 = khg_decode_one(bits, sh.lut, lut2, left, right, tsym, rpos, &s);
+                    const uint32_t l2 = khg_decode_one(bits, glut, lut2, left, right, tsym, rpos, &s);
                     if (l2 == 0) {
                         rdead = true;
                         ract = false;

@@ -47,7 +47,8 @@ static int khg_decode_enqueue(khg_ctx* c, const uint8_t* d_comp, size_t len, int
     // the three streams together are shorter than the file, and each ends inside one more workgroup at most
     uint64_t spanned = (8ull * len) / KHG_BLK_BITS + 3;
     const unsigned grid_dec = (unsigned)(spanned < d.nblocks ? spanned : d.nblocks);
-    hipLaunchKernelGGL(khg_dec_map_kernel, dim3(grid_dec), dim3(256), 0, st, d);
+    hipLaunchKernelGGL((khg_dec_map_kernel<KHG_MAP_SMALL>), dim3(grid_dec), dim3(256), 0, st, d);
+    hipLaunchKernelGGL((khg_dec_map_kernel<KHG_MAXOFF>), dim3(grid_dec), dim3(256), 0, st, d);
     hipLaunchKernelGGL(khg_dec_chain_kernel, dim3(3), dim3(256), 0, st, d);
     hipLaunchKernelGGL(khg_dec_write_kernel, dim3(grid_dec), dim3(256), 0, st, d);
     KhgFwdGrid gr;

@@ -86,11 +86,14 @@ __device__ __forceinline__ uint32_t khg_dec_dispatch_order(const KhgDecArgs& a, 
     return ~0u;
 }
 
+// MO = KHG_MAP_SMALL: planes whose longest code has at most 32 bits (three workgroups per CU);
+// MO = KHG_MAXOFF: the others.  Both are launched; a workgroup of the wrong one returns at once.
+template <int MO>
 __global__ __launch_bounds__(256) void khg_dec_map_kernel(KhgDecArgs a)
 {
-    __shared__ KhgDecSmem sh;
+    __shared__ KhgDecSmem<MO> sh;
     const uint32_t blk = khg_dec_dispatch_order(a, blockIdx.x);
-    if (blk != ~0u) khg_dec_map_body(a, blk, sh);
+    if (blk != ~0u) khg_dec_map_body<MO>(a, blk, sh);
 }
 
 __global__ __launch_bounds__(256) void khg_dec_chain_kernel(KhgDecArgs a)

@@ -124,14 +124,17 @@ static int sim_decode(SimWs& S, const uint8_t* comp, size_t len, int rows, int c
     KhgDecTreeSmem* tsh = new KhgDecTreeSmem;
     for (int p = 0; p < 3; ++p) khg_dec_tree_body(d, p, *tsh);
     delete tsh;
-    KhgDecSmem* lsh = new KhgDecSmem;
+    KhgDecSmem<KHG_MAP_SMALL>* lsh = new KhgDecSmem<KHG_MAP_SMALL>;
+    KhgDecSmem<KHG_MAXOFF>* lsh2 = new KhgDecSmem<KHG_MAXOFF>;
     KhgDecWriteSmem* wsh = new KhgDecWriteSmem;
     KhgDecChainSmem* ssh = new KhgDecChainSmem;
-    for (uint32_t b_ = 0; b_ < d.nblocks; ++b_) khg_dec_map_body(d, b_, *lsh);
+    for (uint32_t b_ = 0; b_ < d.nblocks; ++b_) khg_dec_map_body<KHG_MAP_SMALL>(d, b_, *lsh);
+    for (uint32_t b_ = 0; b_ < d.nblocks; ++b_) khg_dec_map_body<KHG_MAXOFF>(d, b_, *lsh2);
     for (int p = 0; p < 3; ++p) khg_dec_chain_body(d, p, *ssh);
     if (passes_used) *passes_used = 1;
     for (uint32_t b_ = 0; b_ < d.nblocks; ++b_) khg_dec_write_body(d, b_, *wsh);
     delete lsh;
+    delete lsh2;
     delete wsh;
     delete ssh;
     KhgInvSmem* ish = new KhgInvSmem;
