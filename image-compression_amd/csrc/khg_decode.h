@@ -757,25 +757,63 @@ KHG_DEV void khg_dec_map_body(const KhgDecArgs& a, uint32_t blk, KhgDecSmem<MO>&
 #endif
     }
     KHG_BARRIER();
+    // Compose the 256 subsequence maps.  For a workgroup entered at offset o the result is its own map entry
+    // (landing offset, codewords) and, for every subsequence t, the offset it is entered at and the codewords
+    // before it: walk[t * M + o] = (entry offset << 24) | count.  Once the chain has fixed the workgroup's true
+    // entry offset, column o of this table is all the write kernel needs to start 256 independent decoders.
+    // Composition is associative, so it goes in three short sweeps instead of one of 256 dependent steps:
+    // 16 groups of 16 subsequences are composed for every entry offset (one lane per group and offset), one lane
+    // per o chains the 16 group maps, and the first sweep is repeated from the true group entries to write the
+    // table.  The start masks are dead by now and lend their memory to the two small tables.
+    uint32_t* gmap = sh.mask;            // [16][MO]: group g entered at o -> (landing offset << 24) | codewords
+    uint32_t* gent = sh.mask + 16 * MO;  // [16][MO]: workgroup entered at o -> state at the start of group g
     KHG_FOR_THREADS(256)
     {
-        // compose the 256 subsequence maps: one lane per start offset of the workgroup.  Along the way the
-        // lane notes, for every subsequence, the offset it is entered at and the codewords before it:
-        // walk[t * M + o] = (entry offset << 24) | count, for a workgroup entered at offset o.  Once the
-        // chain has fixed the workgroup's true entry offset, column o of this table is all the write
-        // kernel needs to start 256 independent decoders.
-        if ((uint32_t)tid < M) {
-            uint32_t* gw = a.walk + (size_t)blk * KHG_MAXOFF * KHG_DEC_BLOCK;
-            uint32_t off = (uint32_t)tid, tot = 0;
-            for (uint32_t t = 0; t < KHG_DEC_BLOCK; ++t) {
-                gw[t * M + (uint32_t)tid] = (off << 24) | tot;
+        for (uint32_t idx = (uint32_t)tid; idx < 16 * M; idx += 256) {
+            const uint32_t g = idx / M, o = idx - g * M;
+            uint32_t off = o, tot = 0;
+            for (uint32_t t = 16 * g; t < 16 * g + 16; ++t) {
                 if (off != KHG_OFF_NONE) {
-                    uint16_t e = sh.map[off * KHG_DEC_BLOCK + t];
+                    const uint16_t e = sh.map[off * KHG_DEC_BLOCK + t];
                     tot += khg_map_cnt(e);
                     off = khg_map_arr(e);
                 }
             }
+            gmap[g * MO + o] = (off << 24) | tot;
+        }
+    }
+    KHG_BARRIER();
+    KHG_FOR_THREADS(256)
+    {
+        if ((uint32_t)tid < M) {
+            uint32_t off = (uint32_t)tid, tot = 0;
+            for (uint32_t g = 0; g < 16; ++g) {
+                gent[g * MO + (uint32_t)tid] = (off << 24) | tot;
+                if (off != KHG_OFF_NONE) {
+                    const uint32_t v = gmap[g * MO + off];
+                    tot += v & 0xFFFFFFu;
+                    off = v >> 24;
+                }
+            }
             a.blk[blk].map[tid] = (off << 24) | tot;
+        }
+    }
+    KHG_BARRIER();
+    KHG_FOR_THREADS(256)
+    {
+        uint32_t* gw = a.walk + (size_t)blk * KHG_MAXOFF * KHG_DEC_BLOCK;
+        for (uint32_t idx = (uint32_t)tid; idx < 16 * M; idx += 256) {
+            const uint32_t g = idx / M, o = idx - g * M;
+            const uint32_t v = gent[g * MO + o];
+            uint32_t off = v >> 24, tot = v & 0xFFFFFFu;
+            for (uint32_t t = 16 * g; t < 16 * g + 16; ++t) {
+                gw[t * M + o] = (off << 24) | tot;
+                if (off != KHG_OFF_NONE) {
+                    const uint16_t e = sh.map[off * KHG_DEC_BLOCK + t];
+                    tot += khg_map_cnt(e);
+                    off = khg_map_arr(e);
+                }
+            }
         }
 #ifdef KHG_TIMING
         if (tid == 0) {  // developer build: workgroup start / end stamps (100 MHz), read back by khg_debug_blocks
