@@ -26,9 +26,10 @@
 #include "khg_huffman.h"
 
 // Bits per subsequence, a build-time choice (power of two, 128..512).  Measured on 8K frames: 256 shortens one
-// frame's decode (map 410 -> 265 us, write 155 -> 117 us: half as long serial chains per lane in the stretches
-// that need one run per residue class) but costs 5 % of batch throughput (twice the first-codeword work and
-// workgroup records); 512 is the better trade for the pipelined batch this library is benchmarked on.
+// frame's decode (map 290 -> 157 us, write 73 -> 55 us, chain 35 -> 66 us: half as long serial chains per lane in
+// the stretches that need one run per residue class, twice the workgroups to chain) but costs 2 % of batch
+// throughput (twice the first-codeword work and workgroup records); 512 is the better trade for the pipelined
+// batch this library is benchmarked on.
 #ifndef KHG_SUB_BITS_CFG
 #define KHG_SUB_BITS_CFG 512
 #endif
