@@ -99,6 +99,14 @@ def test_long_codes(codec):
     assert np.array_equal(codec.decode(comp), O.decode(comp))
 
 
+def test_codes_beyond_32_bits(codec):
+    """Longest code 44 bits: the map kernel's 56-offset instantiation handles the luma plane."""
+    import craft
+    import oracle_py as O
+    comp = craft.long_code_comp(512, 512, 1, depth=44)
+    assert np.array_equal(codec.decode(comp), O.decode(comp))
+
+
 def test_malformed_files_are_rejected(codec):
     import oracle_py as O
     from khugle_amd import synth_frame, KhgError

@@ -79,6 +79,17 @@ def test_decode_long_codes():
     assert np.array_equal(out, O.decode(comp))
 
 
+def test_decode_codes_beyond_32_bits():
+    """A plane whose longest code exceeds 32 bits is mapped by the kernel's wide instantiation (56 start offsets),
+    the other planes of the same file by the compact one."""
+    comp = craft.long_code_comp(128, 128, 1, depth=44)
+    rc, out, q, _ = S.decode(comp, 128, 128)
+    assert rc == 0
+    (wq, _) = O.decode_planes(comp)
+    assert np.array_equal(q[0].astype(np.int32), wq[0])
+    assert np.array_equal(out, O.decode(comp))
+
+
 def test_output_capacity_is_checked():
     rgb = synth_frame(64, 64, 1, 0)
     rc, _ = S.encode(rgb, 0, cap=64)
