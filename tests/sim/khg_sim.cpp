@@ -325,6 +325,14 @@ void khgsim_synth(uint8_t* r, uint8_t* g, uint8_t* b, int rows, int cols, uint32
 
 // Arithmetic shortcuts against the operations they replace: out_div[i] = khg_div_const(x[i], c, 1/c),
 // out_round[i] = the quantiser's rounding of x[i] / d[i]; fast[i] = 1 when no division was needed.
+// host-side planning: segment height and count chosen for a transform of ph rows
+void khgsim_strip_grid(int ph, int nstrip, int slots, int halo, int max_rows, int* seg_rows, int* nseg)
+{
+    KhgFwdGrid g = khg_strip_grid(ph, nstrip, slots, halo, max_rows);
+    *seg_rows = g.seg_rows;
+    *nseg = g.nseg;
+}
+
 void khgsim_div_const(const double* x, size_t n, double c, double* out_div)
 {
     const double rc = 1 / c;

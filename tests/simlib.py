@@ -106,6 +106,16 @@ def synth(rows, cols, seed, index):
     return out
 
 
+def strip_grid(ph, nstrip, slots, halo, max_rows):
+    """(seg_rows, nseg) the host planner picks for a transform of ph rows."""
+    seg = C.c_int(); nseg = C.c_int()
+    L = lib()
+    L.khgsim_strip_grid.argtypes = [C.c_int] * 5 + [C.POINTER(C.c_int)] * 2
+    L.khgsim_strip_grid.restype = None
+    L.khgsim_strip_grid(ph, nstrip, slots, halo, max_rows, C.byref(seg), C.byref(nseg))
+    return seg.value, nseg.value
+
+
 def div_const(x, c):
     x = np.ascontiguousarray(x, np.float64)
     out = np.empty_like(x)

@@ -90,6 +90,27 @@ def test_decode_codes_beyond_32_bits():
     assert np.array_equal(out, O.decode(comp))
 
 
+def test_strip_grid_plans_whole_batches():
+    """The planner covers every row with even segments inside the limits, and counts cost in whole 16-row batches:
+    no other segment height has a shorter critical path (rounds x batches), nor the same with fewer batches in all."""
+    for ph in (8, 40, 264, 1080, 2160, 4320, 5760):
+        for nstrip, slots, max_rows in ((1, 1024, 128), (8, 768, 128), (30, 1024, 128), (32, 1280, 512)):
+            seg, nseg = S.strip_grid(ph, nstrip, slots, 8, max_rows)
+            assert seg % 2 == 0 and seg * nseg >= ph and seg * (nseg - 1) < ph
+            if ph >= 32:
+                assert 32 <= seg <= max_rows or nseg == 1
+
+                def cost(s_):
+                    n_ = -(-ph // s_)
+                    rounds, batches = -(-nstrip * n_ // slots), -(-(s_ + 8) // 16)
+                    return rounds * batches, nstrip * n_ * batches
+                best = cost(seg)
+                for n_ in range(max(1, -(-ph // max_rows)), ph // 32 + 1):
+                    s_ = (-(-ph // n_) + 1) & ~1
+                    if s_ <= max_rows:
+                        assert cost(s_) >= best, (ph, nstrip, slots, seg, s_)
+
+
 def test_output_capacity_is_checked():
     rgb = synth_frame(64, 64, 1, 0)
     rc, _ = S.encode(rgb, 0, cap=64)
