@@ -1,6 +1,7 @@
 #!/bin/bash
 # The kernel bodies under AddressSanitizer: builds the test-only simulator with -fsanitize=address and no slack on
-# its workspace arrays, and runs the simulator tests (encode, decode, tiles, plane entry points) against it.
+# its workspace arrays, and runs the simulator tests (encode, decode, tiles, plane entry points) against it, then
+# 300 corrupted files through the decoder (tools/fuzz_sim.py).
 # Host code only; catches out-of-bounds indexing in the kernel sources before they reach a GPU.
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
@@ -18,3 +19,4 @@ sys.exit(pytest.main(["$ROOT/tests/test_sim_kernels.py", "$ROOT/tests/test_tiled
                       "-p", "no:cacheprovider"]))
 PY
 ASAN_OPTIONS=detect_leaks=0 LD_PRELOAD=$(g++ -print-file-name=libasan.so) python /tmp/run_asan_suite.py
+KHG_SIM_SO=$SO ASAN_OPTIONS=detect_leaks=0 LD_PRELOAD=$(g++ -print-file-name=libasan.so) python "$ROOT/tools/fuzz_sim.py" 1 300
