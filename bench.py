@@ -114,6 +114,10 @@ def main():
     ap.add_argument("--hw-queues", type=int, default=0,
                     help="HIP hardware queues for this process (GPU_MAX_HW_QUEUES); 0 = one per stream, at most 16")
     args = ap.parse_args()
+    # One process per GPU.  Under torch.distributed.run the ranks exist already; started plainly with --gpus N > 1
+    # this process becomes the parent that starts N ranks (and never touches the GPU itself).
+    from khugle_amd.launch import ranks_or_spawn
+    rank, local_rank, world = ranks_or_spawn(args.gpus)
     # Streams that share a hardware queue run their kernels strictly one after another, single-workgroup
     # table/tree kernels included; with a queue per stream those hide behind other frames' wide kernels.
     # Read by the HIP runtime when it initialises, so it is set before torch is imported.
@@ -125,9 +129,6 @@ def main():
     import khugle_amd
     from khugle_amd.shard import frame_range, max_over_ranks, whole_job_rate
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the codec has no CPU path)")
     torch.cuda.set_device(local_rank)
@@ -135,6 +136,7 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
+        assert dist.get_world_size() == args.gpus
 
     rows, cols, F, S = args.rows, args.cols, args.frames, max(1, min(args.streams, args.frames))
     px = rows * cols

@@ -32,15 +32,16 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--virtual", type=int, default=0, help="rehearse this many ranks on one GPU (threads)")
+    ap.add_argument("--gpus", type=int, default=0,
+                    help="ranks (one process per GPU); started plainly, this process launches them itself")
     args = ap.parse_args()
+    from khugle_amd.launch import ranks_or_spawn
+    rank, local_rank, world = ranks_or_spawn(args.gpus or int(os.environ.get("WORLD_SIZE", "1")))
 
     import torch
     import torch.distributed as dist
     from khugle_amd import Codec, tiled
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench_tiled.py needs a HIP device (the codec has no CPU path)")
     torch.cuda.set_device(local_rank)

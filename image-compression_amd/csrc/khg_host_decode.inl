@@ -40,6 +40,7 @@ static int khg_decode_enqueue(khg_ctx* c, const uint8_t* d_comp, size_t len, int
     if (len < 36 + 24) return KHG_ERR_FORMAT;
     hipStream_t st = (hipStream_t)stream;
     KHG_HIP(hipSetDevice(c->device));
+    if ((rc = khg_begin(c, st))) return rc;
     const KhgDecArgs d = khg_dec_args(c->ws, c->dws, d_comp, len, rows, cols);
     KHG_HIP(hipMemsetAsync(c->ws.res, 0, sizeof(KhgResult), st));
     hipLaunchKernelGGL(khg_dec_header_kernel, dim3(1), dim3(256), 0, st, d);
@@ -70,10 +71,7 @@ static int khg_decode_enqueue(khg_ctx* c, const uint8_t* d_comp, size_t len, int
     }
     KHG_HIP(hipGetLastError());
     KHG_HIP(hipMemcpyAsync(c->h_res, c->ws.res, sizeof(KhgResult), hipMemcpyDeviceToHost, st));
-    KHG_HIP(hipEventRecord(c->done, st));
-    c->last_stream = st;
-    c->pending = 2;
-    return KHG_OK;
+    return khg_end(c, st, 2);
 }
 
 extern "C" int khg_decode_dev(khg_ctx* c, const uint8_t* d_comp, size_t len, int rows, int cols, uint8_t* d_r,

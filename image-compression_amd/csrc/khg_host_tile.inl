@@ -43,26 +43,32 @@ extern "C" int khg_tile_forward_dev(khg_ctx* c, const uint8_t* d_r, const uint8_
     hipStream_t st = (hipStream_t)stream;
     KHG_HIP(hipSetDevice(c->device));
     const KhgTile t = {rank, nranks};
+    if ((rc = khg_begin(c, st))) return rc;
     c->tile = t;
     c->tile_rows = rows; c->tile_cols = cols; c->tile_lvl = lvl;
-    return khg_enqueue_forward(c, d_r, d_g, d_b, rows, cols, lvl, nullptr, st, t);
+    if ((rc = khg_enqueue_forward(c, d_r, d_g, d_b, rows, cols, lvl, nullptr, st, t))) return rc;
+    return khg_end(c, st, 0);
 }
 
 // Partial (get) / image-wide (set) histogram: counts and first raster indices, 3 x 16384 words each.
 extern "C" int khg_tile_hist_get(khg_ctx* c, uint32_t* d_count, uint32_t* d_first, void* stream)
 {
     if (!c || !d_count || !d_first) return KHG_ERR_ARG;
+    int rc = khg_begin(c, (hipStream_t)stream);
+    if (rc) return rc;
     KHG_HIP(hipMemcpyAsync(d_count, c->ws.hist_cnt, 3 * KHG_NBINS * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     KHG_HIP(hipMemcpyAsync(d_first, c->ws.hist_first, 3 * KHG_NBINS * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
-    return KHG_OK;
+    return khg_end(c, (hipStream_t)stream, 0);
 }
 
 extern "C" int khg_tile_hist_set(khg_ctx* c, const uint32_t* d_count, const uint32_t* d_first, void* stream)
 {
     if (!c || !d_count || !d_first) return KHG_ERR_ARG;
+    int rc = khg_begin(c, (hipStream_t)stream);
+    if (rc) return rc;
     KHG_HIP(hipMemcpyAsync(c->ws.hist_cnt, d_count, 3 * KHG_NBINS * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     KHG_HIP(hipMemcpyAsync(c->ws.hist_first, d_first, 3 * KHG_NBINS * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
-    return KHG_OK;
+    return khg_end(c, (hipStream_t)stream, 0);
 }
 
 // Table, tree and codes from the image-wide histogram (identical on every rank), then the bit counts of this
@@ -72,29 +78,35 @@ extern "C" int khg_tile_lens_dev(khg_ctx* c, void* stream)
     if (!c || c->tile.nranks < 1) return KHG_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     KHG_HIP(hipSetDevice(c->device));
+    int rc = khg_begin(c, st);
+    if (rc) return rc;
     KhgTableArgs t = khg_table_args(c->ws);
     hipLaunchKernelGGL(khg_table_kernel, dim3(3), dim3(256), 0, st, t);
     KhgEncArgs e = khg_enc_args(c->ws, c->tile_rows, c->tile_cols, c->tile_lvl, nullptr, 0, c->tile);
     KHG_HIP(hipMemsetAsync(c->ws.chunk_bits, 0, (size_t)e.nchunks * 4, st));
     hipLaunchKernelGGL(khg_lens_kernel, dim3(e.nchunks), dim3(256), 0, st, e);
     KHG_HIP(hipGetLastError());
-    return KHG_OK;
+    return khg_end(c, st, 0);
 }
 
 extern "C" int khg_tile_bits_get(khg_ctx* c, uint32_t* d_bits, void* stream)
 {
     if (!c || !d_bits || c->tile.nranks < 1) return KHG_ERR_ARG;
     size_t n = khg_tile_chunk_count(c->tile_rows, c->tile_cols, c->tile.nranks);
+    int rc = khg_begin(c, (hipStream_t)stream);
+    if (rc) return rc;
     KHG_HIP(hipMemcpyAsync(d_bits, c->ws.chunk_bits, n * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
-    return KHG_OK;
+    return khg_end(c, (hipStream_t)stream, 0);
 }
 
 extern "C" int khg_tile_bits_set(khg_ctx* c, const uint32_t* d_bits, void* stream)
 {
     if (!c || !d_bits || c->tile.nranks < 1) return KHG_ERR_ARG;
     size_t n = khg_tile_chunk_count(c->tile_rows, c->tile_cols, c->tile.nranks);
+    int rc = khg_begin(c, (hipStream_t)stream);
+    if (rc) return rc;
     KHG_HIP(hipMemcpyAsync(c->ws.chunk_bits, d_bits, n * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
-    return KHG_OK;
+    return khg_end(c, (hipStream_t)stream, 0);
 }
 
 // Offsets of all chunks (from the completed bit counts), then this rank's share of the file: its chunks' bits at
@@ -107,16 +119,15 @@ extern "C" int khg_tile_pack_dev(khg_ctx* c, uint8_t* d_out, size_t cap, void* s
     if (cap < 40) return KHG_ERR_CAP;
     hipStream_t st = (hipStream_t)stream;
     KHG_HIP(hipSetDevice(c->device));
+    int rc = khg_begin(c, st);
+    if (rc) return rc;
     KhgEncArgs e = khg_enc_args(c->ws, c->tile_rows, c->tile_cols, c->tile_lvl, d_out, cap, c->tile);
     KHG_HIP(hipMemsetAsync(d_out, 0, cap & ~(size_t)3, st));
     hipLaunchKernelGGL(khg_scan_kernel, dim3(1), dim3(1024), 0, st, e);
     hipLaunchKernelGGL(khg_pack_kernel, dim3(e.nchunks), dim3(256), 0, st, e);
     KHG_HIP(hipGetLastError());
     KHG_HIP(hipMemcpyAsync(c->h_res, c->ws.res, sizeof(KhgResult), hipMemcpyDeviceToHost, st));
-    KHG_HIP(hipEventRecord(c->done, st));
-    c->last_stream = st;
-    c->pending = 1;
-    return KHG_OK;
+    return khg_end(c, st, 1);
 }
 
 // Decode of a tiled image: every rank decodes the whole entropy-coded stream (it cannot be split before it is

@@ -149,8 +149,9 @@ struct khg_ctx {
     void* slab;          // one device allocation carved into the workspace
     size_t slab_bytes;
     KhgResult* h_res;    // pinned host copy of ws.res
-    hipEvent_t done;
+    hipEvent_t done;     // recorded behind the last work enqueued on this context
     hipStream_t last_stream;
+    int used;            // `done` has been recorded at least once
     int pending;         // an encode/decode was enqueued and its result not yet fetched
     // lazily allocated staging for the host-pointer entry points
     uint8_t* stage_rgb;  // 3 planes
@@ -183,6 +184,7 @@ extern "C" const char* khg_status_string(int status)
     case KHG_ERR_NOMEM: return "out of memory";
     case KHG_ERR_HIP: return "HIP runtime error or no device";
     case KHG_ERR_ARG: return "bad argument";
+    case KHG_ERR_BUSY: return "context has a job whose result was not fetched";
     default: return "unknown status";
     }
 }
@@ -241,7 +243,10 @@ extern "C" int khg_ctx_create(int device, int max_rows, int max_cols, khg_ctx** 
     c->dws.hdr = (KhgDecHeader*)(base + o_hdr);
     c->ssim_blocks = (double*)(base + o_ssim);
     c->sse = (unsigned long long*)(base + o_sse);
-    if (hipMemset(c->slab, 0, total) != hipSuccess || hipHostMalloc((void**)&c->h_res, sizeof(KhgResult)) != hipSuccess ||
+    // hipMemset of device memory may return before the fill has run, and the fill is on the null stream, which
+    // non-blocking streams do not wait for: drain it here, so that no work of the caller can overtake it.
+    if (hipMemset(c->slab, 0, total) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess ||
+        hipHostMalloc((void**)&c->h_res, sizeof(KhgResult)) != hipSuccess ||
         hipEventCreateWithFlags(&c->done, hipEventDisableTiming) != hipSuccess) {
         khg_ctx_destroy(c);
         return KHG_ERR_HIP;
@@ -271,6 +276,28 @@ static int khg_check_image(const khg_ctx* c, int rows, int cols)
 {
     if (!c) return KHG_ERR_ARG;
     if (!khg_dims_ok(rows, cols) || rows > c->max_rows || cols > c->max_cols) return KHG_ERR_DIMS;
+    return KHG_OK;
+}
+
+// A context owns one workspace and one result block, so its jobs must not overlap.  Every entry point that
+// enqueues device work on a context calls khg_begin() before its first enqueue and khg_end() after its last:
+//   - while the result of an encode / decode has not been fetched (khg_encode_result, khg_last_status) new work
+//     is refused (KHG_ERR_BUSY): it would overwrite the result block and its pinned host copy;
+//   - work enqueued on another stream than the context's previous work waits (on the device) for that work's
+//     completion event, so a change of stream cannot let two jobs run side by side in one workspace.
+static int khg_begin(khg_ctx* c, hipStream_t st)
+{
+    if (c->pending) return KHG_ERR_BUSY;
+    if (c->used && st != c->last_stream) KHG_HIP(hipStreamWaitEvent(st, c->done, 0));
+    return KHG_OK;
+}
+
+static int khg_end(khg_ctx* c, hipStream_t st, int pending)
+{
+    KHG_HIP(hipEventRecord(c->done, st));
+    c->last_stream = st;
+    c->used = 1;
+    c->pending = pending;
     return KHG_OK;
 }
 
@@ -351,10 +378,7 @@ static int khg_enqueue_entropy(khg_ctx* c, int rows, int cols, int lvl, uint8_t*
     hipLaunchKernelGGL(khg_pack_kernel, dim3(e.nchunks), dim3(256), 0, st, e);
     KHG_HIP(hipGetLastError());
     KHG_HIP(hipMemcpyAsync(c->h_res, c->ws.res, sizeof(KhgResult), hipMemcpyDeviceToHost, st));
-    KHG_HIP(hipEventRecord(c->done, st));
-    c->last_stream = st;
-    c->pending = 1;
-    return KHG_OK;
+    return khg_end(c, st, 1);
 }
 
 static int khg_enqueue_forward(khg_ctx* c, const uint8_t* r, const uint8_t* g, const uint8_t* b, int rows, int cols,
@@ -398,6 +422,7 @@ extern "C" int khg_encode_dev(khg_ctx* c, const uint8_t* d_r, const uint8_t* d_g
     if (cap < 40) return KHG_ERR_CAP;
     hipStream_t st = (hipStream_t)stream;
     KHG_HIP(hipSetDevice(c->device));
+    if ((rc = khg_begin(c, st))) return rc;
     rc = khg_enqueue_forward(c, d_r, d_g, d_b, rows, cols, lvl, nullptr, st);
     if (rc) return rc;
     return khg_enqueue_entropy(c, rows, cols, lvl, d_out, cap, st);
@@ -417,6 +442,7 @@ extern "C" int khg_encode_ycbcr_dev(khg_ctx* c, const double* d_y, const double*
     const double* src[3] = {d_y, d_cb, d_cr};
     double* coef[3] = {d_coef_y, d_coef_cb, d_coef_cr};
     const bool tap = d_coef_y && d_coef_cb && d_coef_cr;
+    if ((rc = khg_begin(c, st))) return rc;
     rc = khg_enqueue_forward_ycbcr(c, src, rows, cols, lvl, tap ? coef : nullptr, st);
     if (rc) return rc;
     return khg_enqueue_entropy(c, rows, cols, lvl, d_out, cap, st);
@@ -485,8 +511,10 @@ extern "C" int khg_forward_planes_dev(khg_ctx* c, const uint8_t* d_r, const uint
     hipStream_t st = (hipStream_t)stream;
     KHG_HIP(hipSetDevice(c->device));
     double* coef[3] = {d_y, d_cb, d_cr};
+    if ((rc = khg_begin(c, st))) return rc;
     rc = khg_enqueue_forward(c, d_r, d_g, d_b, rows, cols, 0, coef, st);
     if (rc) return rc;
+    if ((rc = khg_end(c, st, 0))) return rc;
     KHG_HIP(hipStreamSynchronize(st));
     return KHG_OK;
 }
@@ -499,6 +527,7 @@ extern "C" int khg_symbols_dev(khg_ctx* c, const uint8_t* d_r, const uint8_t* d_
     if (lvl < 0 || lvl > 2) return KHG_ERR_DIMS;
     hipStream_t st = (hipStream_t)stream;
     KHG_HIP(hipSetDevice(c->device));
+    if ((rc = khg_begin(c, st))) return rc;
     rc = khg_enqueue_forward(c, d_r, d_g, d_b, rows, cols, lvl, nullptr, st);
     if (rc) return rc;
     size_t ny = (size_t)rows * cols;
@@ -507,6 +536,7 @@ extern "C" int khg_symbols_dev(khg_ctx* c, const uint8_t* d_r, const uint8_t* d_
         if (dst[p])
             KHG_HIP(hipMemcpyAsync(dst[p], c->ws.sym[p], (p ? ny / 4 : ny) * sizeof(int16_t), hipMemcpyDeviceToDevice, st));
     KHG_HIP(hipMemcpyAsync(c->h_res, c->ws.res, sizeof(KhgResult), hipMemcpyDeviceToHost, st));
+    if ((rc = khg_end(c, st, 0))) return rc;
     KHG_HIP(hipStreamSynchronize(st));
     return c->h_res->status;
 }
@@ -519,6 +549,7 @@ extern "C" int khg_time_luma_forward_dev(khg_ctx* c, const uint8_t* d_r, const u
     if (lvl < 0 || lvl > 2 || reps < 1 || !avg_ms) return KHG_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     KHG_HIP(hipSetDevice(c->device));
+    if ((rc = khg_begin(c, st))) return rc;
     KhgWorkspace& ws = c->ws;
     KHG_HIP(hipMemsetAsync(ws.hist_cnt, 0, 3 * KHG_NBINS * sizeof(uint32_t), st));
     KHG_HIP(hipMemsetAsync(ws.hist_first, 0xFF, 3 * KHG_NBINS * sizeof(uint32_t), st));
@@ -532,12 +563,24 @@ extern "C" int khg_time_luma_forward_dev(khg_ctx* c, const uint8_t* d_r, const u
     KHG_HIP(hipEventRecord(e0, st));
     for (int i = 0; i < reps; ++i) khg_launch_fwd<KHG_SRC_Y, 1>(a, gr, st);
     KHG_HIP(hipEventRecord(e1, st));
+    if ((rc = khg_end(c, st, 0))) return rc;
     KHG_HIP(hipEventSynchronize(e1));
     float ms = 0;
     KHG_HIP(hipEventElapsedTime(&ms, e0, e1));
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     *avg_ms = ms / reps;
+    return KHG_OK;
+}
+
+extern "C" int khg_debug_poison(khg_ctx* c, int byte)
+{
+    if (!c) return KHG_ERR_ARG;
+    if (c->pending) return KHG_ERR_BUSY;
+    KHG_HIP(hipSetDevice(c->device));
+    KHG_HIP(hipDeviceSynchronize());  // whatever stream the context's last work ran on
+    KHG_HIP(hipMemset(c->slab, byte, c->slab_bytes));
+    KHG_HIP(hipDeviceSynchronize());
     return KHG_OK;
 }
 

@@ -79,6 +79,10 @@ class Codec:
         """Waits for the context's last job and returns its device-side status (0 = ok)."""
         return self.L.khg_last_status(self._ctx)
 
+    def debug_poison(self, byte=0xA5):
+        """Test hook: fill the context's whole device workspace with `byte` (stale data of another job)."""
+        _check(self.L.khg_debug_poison(self._ctx, byte), "debug_poison")
+
     def ssim_dev(self, a, b):
         """SSIM of two (H, W) uint8 cuda planes (the reference passes the R channel)."""
         h, w = a.shape

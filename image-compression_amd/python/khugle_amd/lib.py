@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.normpath(os.path.join(_HERE, "..", "..", "csrc"))
 LIB_PATH = os.path.join(CSRC, "libkhugle_hip.so")
 
-OK, ERR_DIMS, ERR_CAP, ERR_FORMAT, ERR_RANGE, ERR_NOMEM, ERR_HIP, ERR_ARG = 0, -1, -2, -3, -4, -5, -6, -7
+OK, ERR_DIMS, ERR_CAP, ERR_FORMAT, ERR_RANGE, ERR_NOMEM, ERR_HIP, ERR_ARG, ERR_BUSY = 0, -1, -2, -3, -4, -5, -6, -7, -8
 
 
 class KhgError(RuntimeError):
@@ -71,6 +71,7 @@ SYMBOLS = [
     ("khg_forward_planes_dev", C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P]),
     ("khg_symbols_dev", C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P]),
     ("khg_time_luma_forward_dev", C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), _P]),
+    ("khg_debug_poison", C.c_int, [_P, C.c_int]),
     ("khg_synth_rows_dev", C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_uint32, _P]),
     ("khg_synth_dev", C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_uint32, C.c_uint32, _P]),
 ]

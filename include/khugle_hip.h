@@ -15,8 +15,12 @@
  *   - "_dev" entry points take DEVICE pointers, enqueue on `stream` (a hipStream_t,
  *     NULL = default stream) and do not synchronise; results are read with
  *     khg_encode_result / khg_last_status.  The others take HOST pointers and are
- *     synchronous.  A context is bound to one device and serialises its own work;
- *     use one context per host thread / per frame in flight.
+ *     synchronous.  A context is bound to one device and owns one workspace, so it runs one job
+ *     at a time: after khg_encode_dev / khg_decode_dev (and their ycbcr / tile forms) every entry
+ *     point that would enqueue more work on the context returns KHG_ERR_BUSY until the result has
+ *     been fetched (khg_encode_result / khg_last_status); work enqueued on a different stream than
+ *     the context's previous work is ordered behind it on the device.  A context is not thread
+ *     safe: use one context per host thread / per frame in flight.
  *   - no entry point falls back to the CPU: without a usable HIP device every call
  *     returns KHG_ERR_HIP.
  */
@@ -39,7 +43,8 @@ typedef enum khg_status {
                                a symbol leaves [-8192, 8191], or a code exceeds 56 bits */
     KHG_ERR_NOMEM = -5,
     KHG_ERR_HIP = -6,       /* no device / HIP runtime error */
-    KHG_ERR_ARG = -7
+    KHG_ERR_ARG = -7,
+    KHG_ERR_BUSY = -8       /* the context holds a job whose result has not been fetched yet */
 } khg_status;
 
 typedef struct khg_ctx khg_ctx;
@@ -171,6 +176,11 @@ int khg_tile_decode_dev(khg_ctx *ctx, const uint8_t *d_comp, size_t len, int row
  * Enabling or disabling resets the tallies. */
 int khg_profile_luma_forward(khg_ctx *ctx, int enable);
 int khg_profile_read(khg_ctx *ctx, double *total_ms, double *total_device_ms, int *launches);
+
+/* ---- test hook (no counterpart in the reference): fills the context's whole device workspace with `byte` and
+ * waits for the fill.  Parity tests call it between jobs to show that no job reads what an earlier job (of the
+ * same or another image size) left behind.  KHG_ERR_BUSY while a result is unfetched. */
+int khg_debug_poison(khg_ctx *ctx, int byte);
 
 /* ---- synthetic frames for benchmarks: deterministic integer arithmetic, identical to
  * khugle_amd.synth.synth_frame on the host.  Device planes. */

@@ -90,10 +90,8 @@ int khgsim_forward(const uint8_t* r, const uint8_t* g, const uint8_t* b, int row
     return S.ws.res->status;
 }
 
-int khgsim_encode(const uint8_t* r, const uint8_t* g, const uint8_t* b, int rows, int cols, int lvl,
-                  uint8_t* out, size_t cap, size_t* out_len) {
-    if (!khg_dims_ok(rows, cols) || lvl < 0 || lvl > 2) return -1;
-    SimWs S(rows, cols);
+static int sim_encode(SimWs& S, const uint8_t* r, const uint8_t* g, const uint8_t* b, int rows, int cols, int lvl,
+                      uint8_t* out, size_t cap, size_t* out_len) {
     forward_all(S, r, g, b, rows, cols, lvl, nullptr);
     KhgTableArgs t = khg_table_args(S.ws);
     KhgTableSmem* tsh = new KhgTableSmem;
@@ -110,6 +108,13 @@ int khgsim_encode(const uint8_t* r, const uint8_t* g, const uint8_t* b, int rows
     delete psh;
     if (out_len) *out_len = (size_t)S.ws.res->total_len;
     return S.ws.res->status;
+}
+
+int khgsim_encode(const uint8_t* r, const uint8_t* g, const uint8_t* b, int rows, int cols, int lvl,
+                  uint8_t* out, size_t cap, size_t* out_len) {
+    if (!khg_dims_ok(rows, cols) || lvl < 0 || lvl > 2) return -1;
+    SimWs S(rows, cols);
+    return sim_encode(S, r, g, b, rows, cols, lvl, out, cap, out_len);
 }
 
 // Mirrors khg_decode_dev / khg_tile_decode_dev (r, g, b receive the tile's rows only) / khg_decode_ycbcr_dev.
@@ -165,6 +170,30 @@ int khgsim_decode(const uint8_t* comp, size_t len, int rows, int cols, uint8_t* 
     if (!khg_dims_ok(rows, cols)) return -1;
     SimWs S(rows, cols);
     return sim_decode(S, comp, len, rows, cols, r, g, b, qy, qcb, qcr, passes_used, KhgTile{0, 1});
+}
+
+// ---- one long-lived workspace, as a khg_ctx has: jobs of any size up to its maximum, one after another, and a
+// poison fill that stands for whatever an earlier job left behind (khg_debug_poison)
+struct SimCtx {
+    SimWs S;
+    int rows, cols;
+    SimCtx(int r, int c) : S(r, c), rows(r), cols(c) {}
+};
+void* khgsim_ctx_create(int rows, int cols) { return khg_dims_ok(rows, cols) ? new SimCtx(rows, cols) : nullptr; }
+void khgsim_ctx_destroy(void* h) { delete (SimCtx*)h; }
+void khgsim_ctx_poison(void* h, int byte) {
+    for (auto& b : ((SimCtx*)h)->S.bufs) memset(b.data(), byte, b.size() - KHG_SIM_SLACK);
+}
+int khgsim_ctx_encode(void* h, const uint8_t* r, const uint8_t* g, const uint8_t* b, int rows, int cols, int lvl,
+                      uint8_t* out, size_t cap, size_t* out_len) {
+    SimCtx* C = (SimCtx*)h;
+    if (!khg_dims_ok(rows, cols) || rows > C->rows || cols > C->cols || lvl < 0 || lvl > 2) return -1;
+    return sim_encode(C->S, r, g, b, rows, cols, lvl, out, cap, out_len);
+}
+int khgsim_ctx_decode(void* h, const uint8_t* comp, size_t len, int rows, int cols, uint8_t* r, uint8_t* g, uint8_t* b) {
+    SimCtx* C = (SimCtx*)h;
+    if (!khg_dims_ok(rows, cols) || rows > C->rows || cols > C->cols) return -1;
+    return sim_decode(C->S, comp, len, rows, cols, r, g, b, nullptr, nullptr, nullptr, nullptr, KhgTile{0, 1});
 }
 
 // Mirrors khg_encode_ycbcr_dev / khg_decode_ycbcr_dev.

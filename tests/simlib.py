@@ -45,6 +45,15 @@ def lib():
         L.khgsim_encode_ycbcr.argtypes = [_f64p, _f64p, _f64p, C.c_int, C.c_int, C.c_int, _u8p, C.c_size_t,
                                           C.POINTER(C.c_size_t), C.c_void_p, C.c_void_p, C.c_void_p]
         L.khgsim_decode_ycbcr.argtypes = [_u8p, C.c_size_t, C.c_int, C.c_int, _f64p, _f64p, _f64p]
+        L.khgsim_ctx_create.argtypes = [C.c_int, C.c_int]
+        L.khgsim_ctx_create.restype = _vp
+        L.khgsim_ctx_destroy.argtypes = [_vp]
+        L.khgsim_ctx_destroy.restype = None
+        L.khgsim_ctx_poison.argtypes = [_vp, C.c_int]
+        L.khgsim_ctx_poison.restype = None
+        L.khgsim_ctx_encode.argtypes = [_vp, _u8p, _u8p, _u8p, C.c_int, C.c_int, C.c_int, _u8p, C.c_size_t,
+                                        C.POINTER(C.c_size_t)]
+        L.khgsim_ctx_decode.argtypes = [_vp, _u8p, C.c_size_t, C.c_int, C.c_int, _u8p, _u8p, _u8p]
         L.khgsim_tile_create.argtypes = [C.c_int, C.c_int]
         L.khgsim_tile_create.restype = _vp
         L.khgsim_tile_destroy.argtypes = [_vp]
@@ -128,6 +137,38 @@ def round_quot(x, d):
     out = np.empty_like(x); fast = np.empty(x.size, np.uint8)
     lib().khgsim_round_quot(x, d, x.size, out, fast)
     return out, fast
+
+
+class SimCtx:
+    """One long-lived simulator workspace (what a khg_ctx is on the GPU): jobs of any size up to its maximum."""
+
+    def __init__(self, rows, cols):
+        self.h = lib().khgsim_ctx_create(rows, cols)
+        assert self.h
+
+    def __del__(self):
+        try:
+            lib().khgsim_ctx_destroy(self.h)
+        except Exception:
+            pass
+
+    def poison(self, byte=0xA5):
+        lib().khgsim_ctx_poison(self.h, byte)
+
+    def encode(self, rgb, lvl):
+        _, h, w = rgb.shape
+        cap = (36 + h * w * 3 + 3 * 16384 * 8 + 3) // 4 * 4
+        out = np.zeros(cap, np.uint8)
+        n = C.c_size_t(0)
+        rgb = np.ascontiguousarray(rgb, np.uint8)
+        rc = lib().khgsim_ctx_encode(self.h, rgb[0], rgb[1], rgb[2], h, w, lvl, out, cap, C.byref(n))
+        return rc, out[:n.value].tobytes() if rc == 0 else b""
+
+    def decode(self, comp, rows, cols):
+        buf = np.frombuffer(comp, np.uint8).copy()
+        out = np.zeros((3, rows, cols), np.uint8)
+        rc = lib().khgsim_ctx_decode(self.h, buf, buf.size, rows, cols, out[0], out[1], out[2])
+        return rc, out
 
 
 class SimTileBackend:
