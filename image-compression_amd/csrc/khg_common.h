@@ -72,9 +72,7 @@ enum {
     KHG_NBINS = 16384,      // dense histogram over symbols [-8192, 8191]
     KHG_SYM_BIAS = 8192,
     KHG_CHUNK = 2048,       // symbols per bit-packing chunk (256 threads x 8)
-    KHG_MAX_CODE_BITS = 56, // code + length share one 64-bit table word
-    KHG_STRIP = 256,        // columns per transform strip (one thread per column)
-    KHG_BATCH = 16          // rows staged per strip batch
+    KHG_MAX_CODE_BITS = 56  // code + length share one 64-bit table word
 };
 
 // Device-side result block of one encode or decode.  A kernel that detects a problem

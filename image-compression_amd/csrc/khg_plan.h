@@ -136,13 +136,6 @@ static inline KhgFwdGrid khg_strip_grid(int ph, int nstrip, int slots, int halo,
     return g;
 }
 
-// Forward transform: 4 (level 1) or 3 (level 2) workgroups per CU by LDS, 256 CUs; the reciprocal-divisor
-// table caps the rows.
-static inline KhgFwdGrid khg_fwd_grid(int ph, int pw, int level)
-{
-    return khg_strip_grid(ph, (pw + KHG_STRIP - 1) / KHG_STRIP, level == 1 ? 1024 : 768, 8, KHG_MAX_SEG_ROWS);
-}
-
 // One tile of a row-tiled image: rank t of n owns image rows [rows*t/n, rows*(t+1)/n), rows/n a multiple of 8
 // so luma and chroma bands line up at both levels.  {0, 1} is the whole image.
 struct KhgTile {
@@ -168,61 +161,143 @@ static inline int khg_tile_in_row1(int rows, KhgTile t)
     return r > rows ? rows : r;
 }
 
-// Forward-transform arguments of colour component comp (0 Y, 1 Cb, 2 Cr) at level 1 or 2.
+// Plane of colour component comp (0 Y, 1 Cb, 2 Cr) at level 1 or 2 of a forward launch, without its grid.
 // coef (optional) is the component's full f64 coefficient plane.
 // Tiles: level 2 of a tile's band [R0/2, R1/2) of the LL quadrant reads LL rows R0/2-4 .. R1/2+4, so level 1 is
 // run over plane rows R0-8 .. R1+8 (symbols emitted for R0 .. R1 only), which reads plane rows R0-12 .. R1+12:
 // 12 luma rows, or 12 chroma rows = 24 image rows, beyond the tile on each side.  r, g, b point at image row
 // khg_tile_in_row0().  Every output is a fixed expression of the inputs, so the recomputed rows are bit-exact.
-static inline KhgFwdArgs khg_fwd_args(const KhgWorkspace& ws, const uint8_t* r, const uint8_t* g, const uint8_t* b,
-                                      int rows, int cols, int lvl, int comp, int level, double* coef,
-                                      KhgFwdGrid* grid, KhgTile tile = KhgTile{0, 1},
-                                      const double* const ycbcr[3] = nullptr)
+static inline void khg_fwd_plane(KhgFwdPlane* pl, const KhgWorkspace& ws, int rows, int cols, int lvl, int comp, int level,
+                                 double* coef, KhgTile tile, const double* src_plane)
 {
-    KhgFwdArgs a;
-    memset(&a, 0, sizeof a);
+    memset(pl, 0, sizeof *pl);
     const int prow = comp ? rows / 2 : rows, pcol = comp ? cols / 2 : cols;  // component plane
-    a.r = r; a.g = g; a.b = b;
-    a.img_w = cols;
     if (level == 1) {
-        a.ph = prow; a.pw = pcol;
-        if (ycbcr) {  // level 1 from caller-supplied f64 Y / Cb / Cr planes instead of RGB (KHG_SRC_PLANE)
-            a.src = ycbcr[comp];
-            a.src_pitch = pcol;
-        }
+        pl->ph = prow; pl->pw = pcol;
+        pl->src = src_plane;  // level 1 from a caller-supplied f64 plane instead of RGB (KHG_SRC_PLANE)
+        pl->src_pitch = pcol;
     } else {
-        a.ph = prow / 2; a.pw = pcol / 2;
-        a.src = ws.ll[comp];
-        a.src_pitch = pcol / 2;
+        pl->ph = prow / 2; pl->pw = pcol / 2;
+        pl->src = ws.ll[comp];
+        pl->src_pitch = pcol / 2;
     }
-    a.ll = ws.ll[comp];
-    a.ll_pitch = pcol / 2;
-    a.sym = ws.sym[comp];
-    a.sym_pitch = pcol;
-    a.coef = coef;
-    a.coef_pitch = pcol;
-    a.hist_cnt = ws.hist_cnt + (size_t)comp * KHG_NBINS;
-    a.hist_first = ws.hist_first + (size_t)comp * KHG_NBINS;
-    a.status = &ws.res->status;
-    a.lvl = lvl;
-    khg_make_quant(rows, cols, lvl, comp != 0, &a.q);
-    a.in_row0 = khg_tile_in_row0(rows, tile);
-    a.in_rows = khg_tile_in_row1(rows, tile) - a.in_row0;
+    pl->ll = ws.ll[comp];
+    pl->ll_pitch = pcol / 2;
+    pl->sym = ws.sym[comp];
+    pl->sym_pitch = pcol;
+    pl->coef = coef;
+    pl->coef_pitch = pcol;
+    pl->hist_cnt = ws.hist_cnt + (size_t)comp * KHG_NBINS;
+    pl->hist_first = ws.hist_first + (size_t)comp * KHG_NBINS;
+    khg_make_quant(rows, cols, lvl, comp != 0, &pl->q);
     const int R0 = khg_tile_row0(prow, tile), R1 = khg_tile_row1(prow, tile);  // the tile's band of this component
     if (level == 1) {
-        a.row_begin = R0 - 8 < 0 ? 0 : R0 - 8;
-        a.row_end = R1 + 8 > prow ? prow : R1 + 8;
-        a.emit_k0 = R0 / 2;
-        a.emit_k1 = R1 / 2;
+        pl->row_begin = R0 - 8 < 0 ? 0 : R0 - 8;
+        pl->row_end = R1 + 8 > prow ? prow : R1 + 8;
+        pl->emit_k0 = R0 / 2;
+        pl->emit_k1 = R1 / 2;
     } else {
-        a.row_begin = R0 / 2;
-        a.row_end = R1 / 2;
-        a.emit_k0 = a.row_begin / 2;
-        a.emit_k1 = a.row_end / 2;
+        pl->row_begin = R0 / 2;
+        pl->row_end = R1 / 2;
+        pl->emit_k0 = pl->row_begin / 2;
+        pl->emit_k1 = pl->row_end / 2;
     }
-    *grid = khg_fwd_grid(a.row_end - a.row_begin, a.pw, level);
-    a.seg_rows = grid->seg_rows;
-    a.nstrip = grid->nstrip;
+}
+
+// Workgroups of the chip that a forward launch is planned for: 4 per CU (4 waves per SIMD) on 256 CUs.
+#ifndef KHG_FWD_SLOTS
+#define KHG_FWD_SLOTS 1024
+#endif
+
+// Grid of a forward launch: ngroup groups of planes (a group shares one grid: Y alone, Cb with Cr), group i
+// starting at plane first[i] and costing weight[i] per row relative to a single plane.  A workgroup walks a segment
+// of its rows plus 8 warm-up rows, so segments should be as tall as the chip allows: the segment heights are the
+// ones at which every group's workgroups carry about the same work and all of them together just fit the chip at
+// once (KHG_FWD_SLOTS), within 16 .. KHG_MAX_SEG_ROWS rows.
+static inline void khg_fwd_plan_grid(KhgFwdArgs* a, int ngroup, const int* first, const int* count, const int* weight)
+{
+    long total = 0;
+    for (int i = 0; i < ngroup; ++i) {
+        KhgFwdPlane& pl = a->pl[first[i]];
+        const int nstrips = (pl.pw / 2 + KHG_STRIP_PAIRS - 1) / KHG_STRIP_PAIRS;
+        pl.nstrip_wg = (nstrips + KHG_WG_STRIPS - 1) / KHG_WG_STRIPS;
+        total += (long)pl.nstrip_wg * (pl.row_end - pl.row_begin) * weight[i];
+    }
+    long T = (total + KHG_FWD_SLOTS - 1) / KHG_FWD_SLOTS;  // weighted rows per workgroup
+    for (;;) {
+        long wgs = 0;
+        bool all_max = true;
+        for (int i = 0; i < ngroup; ++i) {
+            KhgFwdPlane& pl = a->pl[first[i]];
+            const int span = pl.row_end - pl.row_begin;
+            int seg = (int)((T / weight[i] + 1) & ~1L);
+            if (seg < 16) seg = 16;
+            if (seg > KHG_MAX_SEG_ROWS) seg = KHG_MAX_SEG_ROWS;
+            if (seg > span) seg = span;
+            if (seg < KHG_MAX_SEG_ROWS && seg < span) all_max = false;  // this group could still take taller segments
+            int nseg = (span + seg - 1) / seg;
+            seg = ((span + nseg - 1) / nseg + 1) & ~1;  // equal segments
+            nseg = (span + seg - 1) / seg;
+            pl.seg_rows = seg;
+            pl.nseg = nseg;
+            wgs += (long)pl.nstrip_wg * nseg;
+        }
+        if (wgs <= KHG_FWD_SLOTS || all_max || T > 4L * KHG_MAX_SEG_ROWS) break;
+        T += 2;
+    }
+    int wg = 0;
+    for (int i = 0; i < ngroup; ++i) {
+        KhgFwdPlane& pl = a->pl[first[i]];
+        pl.wg0 = wg;
+        for (int j = 1; j < count[i]; ++j) {  // the group's other planes share the grid
+            KhgFwdPlane& o = a->pl[first[i] + j];
+            o.seg_rows = pl.seg_rows; o.nseg = pl.nseg; o.nstrip_wg = pl.nstrip_wg; o.wg0 = wg;
+        }
+        wg += pl.nstrip_wg * pl.nseg;
+    }
+    a->nwg = wg;
+}
+
+static inline void khg_fwd_args_common(KhgFwdArgs* a, const KhgWorkspace& ws, const uint8_t* r, const uint8_t* g,
+                                       const uint8_t* b, int rows, int cols, int lvl, KhgTile tile)
+{
+    memset(a, 0, sizeof *a);
+    a->r = r; a->g = g; a->b = b;
+    a->img_w = cols;
+    a->in_row0 = khg_tile_in_row0(rows, tile);
+    a->in_rows = khg_tile_in_row1(rows, tile) - a->in_row0;
+    a->status = &ws.res->status;
+    a->lvl = lvl;
+}
+
+// Level 1 of all three components from u8 RGB in one launch (KHG_FWD_RGB): luma workgroups, then workgroups that
+// carry Cb and Cr together.  luma_only: just the luma workgroups (a measurement aid).
+static inline KhgFwdArgs khg_fwd_args_rgb(const KhgWorkspace& ws, const uint8_t* r, const uint8_t* g, const uint8_t* b,
+                                          int rows, int cols, int lvl, double* const coef[3],
+                                          KhgTile tile = KhgTile{0, 1}, bool luma_only = false)
+{
+    KhgFwdArgs a;
+    khg_fwd_args_common(&a, ws, r, g, b, rows, cols, lvl, tile);
+    for (int p = 0; p < 3; ++p) khg_fwd_plane(&a.pl[p], ws, rows, cols, lvl, p, 1, coef ? coef[p] : nullptr, tile, nullptr);
+    const int first[2] = {0, 1}, count[2] = {1, 2}, weight[2] = {1, 2};
+    a.nplanes = luma_only ? 1 : 3;
+    khg_fwd_plan_grid(&a, luma_only ? 1 : 2, first, count, weight);
+    return a;
+}
+
+// Level 1 from caller-supplied f64 Y / Cb / Cr planes (KHG_FWD_PLANES1, ycbcr != null) or level 2 from the LL
+// quadrants that level 1 left in the workspace (KHG_FWD_PLANES2): the three components in one launch.
+static inline KhgFwdArgs khg_fwd_args_planes(const KhgWorkspace& ws, int rows, int cols, int lvl, int level,
+                                             double* const coef[3], KhgTile tile = KhgTile{0, 1},
+                                             const double* const ycbcr[3] = nullptr)
+{
+    KhgFwdArgs a;
+    khg_fwd_args_common(&a, ws, nullptr, nullptr, nullptr, rows, cols, lvl, tile);
+    for (int p = 0; p < 3; ++p)
+        khg_fwd_plane(&a.pl[p], ws, rows, cols, lvl, p, level, coef ? coef[p] : nullptr, tile, ycbcr ? ycbcr[p] : nullptr);
+    const int first[3] = {0, 1, 2}, count[3] = {1, 1, 1}, weight[3] = {1, 1, 1};
+    a.nplanes = 3;
+    khg_fwd_plan_grid(&a, 3, first, count, weight);
     return a;
 }
 

@@ -15,13 +15,13 @@
 
 // ------------------------------------------------------------------ kernels
 
-// LDS allows 4 workgroups per CU at level 1 and 3 at level 2; the register bound matches (the kernels are
-// issue- and latency-bound, so resident waves are what they need).
-template <int SRC, int LEVEL>
-__global__ __launch_bounds__(256, LEVEL == 1 ? 4 : 3) void khg_fwd_kernel(KhgFwdArgs a)
+// KIND: KHG_FWD_RGB (level 1 of Y, Cb, Cr from u8 RGB), KHG_FWD_PLANES1 (level 1 from f64 planes),
+// KHG_FWD_PLANES2 (level 2 of the three components).
+template <int KIND>
+__global__ __launch_bounds__(256) void khg_fwd_kernel(KhgFwdArgs a)
 {
-    __shared__ KhgFwdSmem<LEVEL> sh;
-    khg_fwd_strip_body<SRC, LEVEL>(a, (int)blockIdx.x, sh);
+    __shared__ KhgFwdSmemAny sh;
+    khg_fwd_launch_body<KIND>(a, (int)blockIdx.x, sh);
 }
 
 __global__ __launch_bounds__(256) void khg_table_kernel(KhgTableArgs a)
@@ -303,10 +303,10 @@ static int khg_end(khg_ctx* c, hipStream_t st, int pending)
 
 // ------------------------------------------------------------------- encode
 
-template <int SRC, int LEVEL>
-static void khg_launch_fwd(const KhgFwdArgs& a, const KhgFwdGrid& g, hipStream_t st)
+template <int KIND>
+static void khg_launch_fwd(const KhgFwdArgs& a, hipStream_t st)
 {
-    hipLaunchKernelGGL((khg_fwd_kernel<SRC, LEVEL>), dim3(g.nstrip * g.nseg), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((khg_fwd_kernel<KIND>), dim3(a.nwg), dim3(256), 0, st, a);
 }
 
 // Colour + both DWT levels + quantiser + histograms for the three components.
@@ -356,14 +356,8 @@ static int khg_enqueue_forward_ycbcr(khg_ctx* c, const double* const ycbcr[3], i
     KHG_HIP(hipMemsetAsync(ws.hist_cnt, 0, 3 * KHG_NBINS * sizeof(uint32_t), st));
     KHG_HIP(hipMemsetAsync(ws.hist_first, 0xFF, 3 * KHG_NBINS * sizeof(uint32_t), st));
     KHG_HIP(hipMemsetAsync(ws.res, 0, sizeof(KhgResult), st));
-    KhgFwdGrid gr;
-    for (int level = 1; level <= 2; ++level)
-        for (int p = 0; p < 3; ++p) {
-            KhgFwdArgs a = khg_fwd_args(ws, nullptr, nullptr, nullptr, rows, cols, lvl, p, level,
-                                        coef ? coef[p] : nullptr, &gr, KhgTile{0, 1}, level == 1 ? ycbcr : nullptr);
-            if (level == 1) khg_launch_fwd<KHG_SRC_PLANE, 1>(a, gr, st);
-            else khg_launch_fwd<KHG_SRC_PLANE, 2>(a, gr, st);
-        }
+    khg_launch_fwd<KHG_FWD_PLANES1>(khg_fwd_args_planes(ws, rows, cols, lvl, 1, coef, KhgTile{0, 1}, ycbcr), st);
+    khg_launch_fwd<KHG_FWD_PLANES2>(khg_fwd_args_planes(ws, rows, cols, lvl, 2, coef), st);
     KHG_HIP(hipGetLastError());
     return KHG_OK;
 }
@@ -388,26 +382,17 @@ static int khg_enqueue_forward(khg_ctx* c, const uint8_t* r, const uint8_t* g, c
     KHG_HIP(hipMemsetAsync(ws.hist_cnt, 0, 3 * KHG_NBINS * sizeof(uint32_t), st));
     KHG_HIP(hipMemsetAsync(ws.hist_first, 0xFF, 3 * KHG_NBINS * sizeof(uint32_t), st));
     KHG_HIP(hipMemsetAsync(ws.res, 0, sizeof(KhgResult), st));
-    KhgFwdGrid gr;
-    KhgFwdArgs a;
-    a = khg_fwd_args(ws, r, g, b, rows, cols, lvl, 0, 1, coef ? coef[0] : nullptr, &gr, tile);
+    KhgFwdArgs a = khg_fwd_args_rgb(ws, r, g, b, rows, cols, lvl, coef, tile);
     if (c->prof_on) {
         KHG_HIP(hipEventRecord(c->prof_e0, st));
         a.prof = ws.res;
     }
-    khg_launch_fwd<KHG_SRC_Y, 1>(a, gr, st);
+    khg_launch_fwd<KHG_FWD_RGB>(a, st);
     if (c->prof_on) {
         KHG_HIP(hipEventRecord(c->prof_e1, st));
         c->prof_pending = 1;
     }
-    a = khg_fwd_args(ws, r, g, b, rows, cols, lvl, 1, 1, coef ? coef[1] : nullptr, &gr, tile);
-    khg_launch_fwd<KHG_SRC_CB, 1>(a, gr, st);
-    a = khg_fwd_args(ws, r, g, b, rows, cols, lvl, 2, 1, coef ? coef[2] : nullptr, &gr, tile);
-    khg_launch_fwd<KHG_SRC_CR, 1>(a, gr, st);
-    for (int p = 0; p < 3; ++p) {
-        a = khg_fwd_args(ws, r, g, b, rows, cols, lvl, p, 2, coef ? coef[p] : nullptr, &gr, tile);
-        khg_launch_fwd<KHG_SRC_PLANE, 2>(a, gr, st);
-    }
+    khg_launch_fwd<KHG_FWD_PLANES2>(khg_fwd_args_planes(ws, rows, cols, lvl, 2, coef, tile), st);
     KHG_HIP(hipGetLastError());
     return KHG_OK;
 }
@@ -554,14 +539,13 @@ extern "C" int khg_time_luma_forward_dev(khg_ctx* c, const uint8_t* d_r, const u
     KHG_HIP(hipMemsetAsync(ws.hist_cnt, 0, 3 * KHG_NBINS * sizeof(uint32_t), st));
     KHG_HIP(hipMemsetAsync(ws.hist_first, 0xFF, 3 * KHG_NBINS * sizeof(uint32_t), st));
     KHG_HIP(hipMemsetAsync(ws.res, 0, sizeof(KhgResult), st));
-    KhgFwdGrid gr;
-    KhgFwdArgs a = khg_fwd_args(ws, d_r, d_g, d_b, rows, cols, lvl, 0, 1, nullptr, &gr);
+    KhgFwdArgs a = khg_fwd_args_rgb(ws, d_r, d_g, d_b, rows, cols, lvl, nullptr);
     hipEvent_t e0, e1;
     KHG_HIP(hipEventCreate(&e0));
     KHG_HIP(hipEventCreate(&e1));
-    khg_launch_fwd<KHG_SRC_Y, 1>(a, gr, st);  // warm-up
+    khg_launch_fwd<KHG_FWD_RGB>(a, st);  // warm-up
     KHG_HIP(hipEventRecord(e0, st));
-    for (int i = 0; i < reps; ++i) khg_launch_fwd<KHG_SRC_Y, 1>(a, gr, st);
+    for (int i = 0; i < reps; ++i) khg_launch_fwd<KHG_FWD_RGB>(a, st);
     KHG_HIP(hipEventRecord(e1, st));
     if ((rc = khg_end(c, st, 0))) return rc;
     KHG_HIP(hipEventSynchronize(e1));

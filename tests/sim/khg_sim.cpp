@@ -49,10 +49,10 @@ struct SimWs {
     KhgDecWorkspace dws;
 };
 
-template <int SRC, int LEVEL>
-void run_fwd(const KhgFwdArgs& a, const KhgFwdGrid& g) {
-    KhgFwdSmem<LEVEL>* sh = new KhgFwdSmem<LEVEL>;
-    for (int bid = 0; bid < g.nstrip * g.nseg; ++bid) khg_fwd_strip_body<SRC, LEVEL>(a, bid, *sh);
+template <int KIND>
+void run_fwd(const KhgFwdArgs& a) {
+    KhgFwdSmemAny* sh = new KhgFwdSmemAny;
+    for (int wg = 0; wg < a.nwg; ++wg) khg_fwd_launch_body<KIND>(a, wg, *sh);
     delete sh;
 }
 
@@ -62,15 +62,8 @@ void forward_all(SimWs& S, const uint8_t* r, const uint8_t* g, const uint8_t* b,
     memset(ws.hist_cnt, 0, 3 * KHG_NBINS * 4);
     memset(ws.hist_first, 0xFF, 3 * KHG_NBINS * 4);
     memset(ws.res, 0, sizeof(KhgResult));
-    KhgFwdGrid gr;
-    KhgFwdArgs a;
-    a = khg_fwd_args(ws, r, g, b, rows, cols, lvl, 0, 1, coef ? coef[0] : nullptr, &gr, tile); run_fwd<KHG_SRC_Y, 1>(a, gr);
-    a = khg_fwd_args(ws, r, g, b, rows, cols, lvl, 1, 1, coef ? coef[1] : nullptr, &gr, tile); run_fwd<KHG_SRC_CB, 1>(a, gr);
-    a = khg_fwd_args(ws, r, g, b, rows, cols, lvl, 2, 1, coef ? coef[2] : nullptr, &gr, tile); run_fwd<KHG_SRC_CR, 1>(a, gr);
-    for (int c = 0; c < 3; ++c) {
-        a = khg_fwd_args(ws, r, g, b, rows, cols, lvl, c, 2, coef ? coef[c] : nullptr, &gr, tile);
-        run_fwd<KHG_SRC_PLANE, 2>(a, gr);
-    }
+    run_fwd<KHG_FWD_RGB>(khg_fwd_args_rgb(ws, r, g, b, rows, cols, lvl, coef, tile));
+    run_fwd<KHG_FWD_PLANES2>(khg_fwd_args_planes(ws, rows, cols, lvl, 2, coef, tile));
 }
 
 }  // namespace
@@ -207,14 +200,8 @@ int khgsim_encode_ycbcr(const double* y, const double* cb, const double* cr, int
     memset(ws.res, 0, sizeof(KhgResult));
     const double* src[3] = {y, cb, cr};
     double* coef[3] = {coef_y, coef_cb, coef_cr};
-    KhgFwdGrid gr;
-    for (int level = 1; level <= 2; ++level)
-        for (int p = 0; p < 3; ++p) {
-            KhgFwdArgs a = khg_fwd_args(ws, nullptr, nullptr, nullptr, rows, cols, lvl, p, level, coef_y ? coef[p] : nullptr,
-                                        &gr, KhgTile{0, 1}, level == 1 ? src : nullptr);
-            if (level == 1) run_fwd<KHG_SRC_PLANE, 1>(a, gr);
-            else run_fwd<KHG_SRC_PLANE, 2>(a, gr);
-        }
+    run_fwd<KHG_FWD_PLANES1>(khg_fwd_args_planes(ws, rows, cols, lvl, 1, coef_y ? coef : nullptr, KhgTile{0, 1}, src));
+    run_fwd<KHG_FWD_PLANES2>(khg_fwd_args_planes(ws, rows, cols, lvl, 2, coef_y ? coef : nullptr));
     KhgTableArgs t = khg_table_args(ws);
     KhgTableSmem* tsh = new KhgTableSmem;
     for (int p = 0; p < 3; ++p) khg_table_body(t, p, *tsh);
