@@ -124,31 +124,36 @@ KHG_DEV double khg_fwd_scale_even(double x)
 }
 KHG_DEV double khg_fwd_scale_odd(double x) { const double a = 1 / 1.149604398; return x * a; }
 
-// ---- neighbour lanes.  khg_lane_next(v): the value lane l+1 holds, khg_lane_prev(v): lane l-1's; a lane at the
-// end of its wave gets its own value back.
+// ---- neighbour lanes.  khg_lane_next(v): the value lane l+1 holds, khg_lane_prev(v): lane l-1's.  What the lane
+// at the end of a wave receives is unspecified (whatever its destination register held): inside the plane that
+// lane is halo, and at the plane's edge the caller substitutes the lane's own value (the whole-sample mirror).
 #ifndef KHG_SIM
 __device__ __forceinline__ double khg_lane_next(double v)
 {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xf, 0xf, false);  // wave_shl:1
-    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false);
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x130, 0xf, 0xf, false);  // wave_shl:1
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x130, 0xf, 0xf, false);
     return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double khg_lane_prev(double v)
 {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);  // wave_shr:1
-    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x138, 0xf, 0xf, false);  // wave_shr:1
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x138, 0xf, 0xf, false);
     return __hiloint2double(hi, lo);
 }
 // One exchange of a per-thread value: dst = src of the next / previous lane.
 #define KHG_LANE_NEXT(dst, src) KHG_FOR_THREADS(256) { (dst)[KHG_SLOT] = khg_lane_next((src)[KHG_SLOT]); }
 #define KHG_LANE_PREV(dst, src) KHG_FOR_THREADS(256) { (dst)[KHG_SLOT] = khg_lane_prev((src)[KHG_SLOT]); }
+// A value that is the same in every lane of the wave, told to the compiler (it then lives in a scalar register
+// and conditions on it become scalar branches).
+#define KHG_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
+KHG_DEV int khg_f2i(double n) { return (int)n; }  // v_cvt_i32_f64 saturates
 #else
 #define KHG_LANE_NEXT(dst, src) \
     for (int t_ = 0; t_ < 256; ++t_) (dst)[t_] = (t_ & 63) == 63 ? (src)[t_] : (src)[t_ + 1];
 #define KHG_LANE_PREV(dst, src) \
     for (int t_ = 0; t_ < 256; ++t_) (dst)[t_] = (t_ & 63) == 0 ? (src)[t_] : (src)[t_ - 1];
+#define KHG_UNIFORM(x) (x)
+static inline int khg_f2i(double n) { return n >= 2147483647.0 ? 2147483647 : (n <= -2147483648.0 ? (-2147483647 - 1) : (int)n); }
 #endif
 
 // Image row `row` as a row of the r/g/b buffers.  Rows a segment reads beyond those its outputs need may, for a band
@@ -175,16 +180,19 @@ KHG_DEV uint32_t khg_ld32(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p
 template <int SRC>
 KHG_DEV void khg_fwd_fetch(const KhgFwdArgs& a, const KhgFwdPlane& pl, KhgFwdRaw<SRC>& raw, int ya, int yb, int p)
 {
+    // offsets are 32-bit (a plane has fewer than 2^31 samples): a scalar row offset plus the lane's column
     if constexpr (SRC == KHG_SRC_PLANE) {
-        __builtin_memcpy(&raw.w[0], pl.src + (size_t)ya * pl.src_pitch + 2 * p, 16);
-        __builtin_memcpy(&raw.w[4], pl.src + (size_t)yb * pl.src_pitch + 2 * p, 16);
+        __builtin_memcpy(&raw.w[0], pl.src + ((uint32_t)ya * (uint32_t)pl.src_pitch + 2u * (uint32_t)p), 16);
+        __builtin_memcpy(&raw.w[4], pl.src + ((uint32_t)yb * (uint32_t)pl.src_pitch + 2u * (uint32_t)p), 16);
     } else if constexpr (SRC == KHG_SRC_Y) {
-        const size_t oa = (size_t)khg_band_row(a, ya) * a.img_w + 2 * p, ob = (size_t)khg_band_row(a, yb) * a.img_w + 2 * p;
+        const uint32_t oa = (uint32_t)khg_band_row(a, ya) * (uint32_t)a.img_w + 2u * (uint32_t)p;
+        const uint32_t ob = (uint32_t)khg_band_row(a, yb) * (uint32_t)a.img_w + 2u * (uint32_t)p;
         raw.w[0] = khg_ld16(a.r + oa); raw.w[1] = khg_ld16(a.g + oa); raw.w[2] = khg_ld16(a.b + oa);
         raw.w[3] = khg_ld16(a.r + ob); raw.w[4] = khg_ld16(a.g + ob); raw.w[5] = khg_ld16(a.b + ob);
     } else {
         // chroma site (y, x) reads the pixel at (2y, 2x): Colorspace.h:16-21
-        const size_t oa = (size_t)khg_band_row(a, 2 * ya) * a.img_w + 4 * p, ob = (size_t)khg_band_row(a, 2 * yb) * a.img_w + 4 * p;
+        const uint32_t oa = (uint32_t)khg_band_row(a, 2 * ya) * (uint32_t)a.img_w + 4u * (uint32_t)p;
+        const uint32_t ob = (uint32_t)khg_band_row(a, 2 * yb) * (uint32_t)a.img_w + 4u * (uint32_t)p;
         raw.w[0] = khg_ld32(a.r + oa); raw.w[1] = khg_ld32(a.g + oa); raw.w[2] = khg_ld32(a.b + oa);
         raw.w[3] = khg_ld32(a.r + ob); raw.w[4] = khg_ld32(a.g + ob); raw.w[5] = khg_ld32(a.b + ob);
     }
@@ -224,43 +232,111 @@ KHG_DEV void khg_fwd_samples(const KhgFwdRaw<SRC>& raw, int rr, int n, double& e
 // first-appearance index: one LDS atomic per bit, ever.
 typedef uint32_t KhgHot;
 
-// Quantise one coefficient, store the symbol and count it (Compress.h:218-219, Huffman.h:110-139).
-// rdiv = RN(1/divisor) of this position (khg_round_quot_fast); stream 0 = rows k, 1 = rows hh+k.
-template <int LHIST>
-KHG_DEV void khg_quant_store(const KhgFwdArgs& a, const KhgFwdPlane& pl, uint32_t* lcnt, uint32_t* lfirst, KhgHot& hot,
-                             double c, double rdiv, int band, int stream, int y, int x)
+// ---- quantiser (Compress.h:218-219) and symbol table counts (Huffman.h:110-139).
+// The symbols a lane emits for one row pair are quantised together: the common case -- every quotient is clear of a
+// rounding tie and every symbol is -1, 0 or +1 and has been seen in its stream before -- is straight-line code, and
+// everything else is collected behind two rarely taken branches.
+
+// q = round(c / div) from rdiv = RN(1/div), when that is safe: t = c * rdiv is within 2^-51 (relative) of the exact
+// quotient, far less than 1e-5 for every |t| that can become a symbol, so both round to the same integer unless
+// t sits within 1e-5 of a half-integer (then, and for NaN and infinity, the caller divides).  Away from ties
+// round-to-nearest-even and round-half-away agree.  A huge finite t passes and saturates q, which is out of the
+// symbol range and fails the job like the division would.
+KHG_DEV bool khg_quant_try(double c, double rdiv, int* q)
 {
-    double n;
-    if (!khg_round_quot_fast(c, rdiv, &n)) {
-        // near a tie, not finite, or huge: the reference's own division decides
-        n = round(c / khg_divisor(pl.q, band, x, y, a.lvl));
-        if (!(n >= -(double)KHG_SYM_BIAS && n < (double)KHG_SYM_BIAS)) n = (double)KHG_SYM_BIAS;  // flagged below
-    }
-    int q = (int)n;  // saturating: a finite n beyond int range stays out of range
-    if ((unsigned)(q + KHG_SYM_BIAS) >= 2u * KHG_SYM_BIAS) {
-        khg_set_status(a.status, -4);
-        q = 0;
-    }
-    uint32_t raster = (uint32_t)y * (uint32_t)pl.sym_pitch + (uint32_t)x;
-    pl.sym[raster] = (int16_t)q;
+    const double t = c * rdiv;
+    const double n = __builtin_rint(t);
+    *q = khg_f2i(n);
+    return fabs(t - n) < 0.49999;
+}
+
+// The reference's own division, for the coefficients khg_quant_try declines.
+KHG_DEV int khg_quant_divide(const KhgFwdArgs& a, const KhgFwdPlane& pl, double c, int band, int x, int y)
+{
+    double n = round(c / khg_divisor(pl.q, band, x, y, a.lvl));
+    if (!(n >= -(double)KHG_SYM_BIAS && n < (double)KHG_SYM_BIAS)) n = (double)KHG_SYM_BIAS;  // out of range: flagged later
+    return (int)n;
+}
+
+// Tally word of a hot symbol (q in -1..1) in output stream `stream`: its 8-bit counter's unit, and its seen bit.
+KHG_DEV uint32_t khg_hot_unit(uint32_t q1) { return 1u << ((8u * q1) & 31u); }
+KHG_DEV uint32_t khg_hot_seen(uint32_t q1, int stream) { return 1u << ((24u + 2u * q1 + (uint32_t)stream) & 31u); }
+
+// Count one symbol that the straight-line path could not finish: a hot symbol's first appearance in its stream
+// (its unit was added already), or any other symbol.  Returns the symbol to store (0 when out of range).
+template <int LHIST>
+KHG_DEV int khg_count_rare(const KhgFwdArgs& a, const KhgFwdPlane& pl, uint32_t* lcnt, uint32_t* lfirst, KhgHot& hot, int q,
+                           int stream, uint32_t raster)
+{
     const uint32_t q1 = (uint32_t)(q + 1);
     if (q1 <= 2u) {
-        hot += 1u << (8 * q1);
-        const uint32_t bit = 1u << (24 + 2 * q1 + stream);
+        const uint32_t bit = khg_hot_seen(q1, stream);
         if (!(hot & bit)) {
             hot |= bit;
             khg_lds_min(&lfirst[q + LHIST / 2], raster);
         }
+        return q;
+    }
+    if ((unsigned)(q + KHG_SYM_BIAS) >= 2u * KHG_SYM_BIAS) {
+        khg_set_status(a.status, -4);
+        q = 0;  // stored and counted as a zero; the job fails with KHG_ERR_RANGE
+        hot += khg_hot_unit(1u);
+        const uint32_t bit = khg_hot_seen(1u, stream);
+        if (!(hot & bit)) {
+            hot |= bit;
+            khg_lds_min(&lfirst[LHIST / 2], raster);
+        }
+        return q;
+    }
+    const int l = q + LHIST / 2;
+    if ((unsigned)l < (unsigned)LHIST) {
+        khg_lds_add(&lcnt[l], 1u);
+        khg_lds_min(&lfirst[l], raster);
     } else {
-        const int l = q + LHIST / 2;
-        if ((unsigned)l < (unsigned)LHIST) {
-            khg_lds_add(&lcnt[l], 1u);
-            khg_lds_min(&lfirst[l], raster);
-        } else {
-            khg_atomic_add(&pl.hist_cnt[q + KHG_SYM_BIAS], 1u);
-            khg_atomic_min(&pl.hist_first[q + KHG_SYM_BIAS], raster);
+        khg_atomic_add(&pl.hist_cnt[q + KHG_SYM_BIAS], 1u);
+        khg_atomic_min(&pl.hist_first[q + KHG_SYM_BIAS], raster);
+    }
+    return q;
+}
+
+// NS coefficients c[i] of one lane and row pair, in raster order within each output stream: band[i], reciprocal
+// divisor rd[i], position (y[i], x[i]) -- used only off the fast path -- and byte offset so + boff[i] in the symbol
+// plane.  Quantises, stores and counts them.
+template <int NS, int LHIST>
+KHG_DEV void khg_quant_emit(const KhgFwdArgs& a, const KhgFwdPlane& pl, uint32_t* lcnt, uint32_t* lfirst, KhgHot& hot,
+                            const double* c, const double* rd, const int* band, const int* stream, const int* y,
+                            const int* x, uint32_t so, const uint32_t* boff)
+{
+    int q[NS];
+    bool clear = true;
+    KHG_UNROLL
+    for (int i = 0; i < NS; ++i) clear = khg_quant_try(c[i], rd[i], &q[i]) && clear;
+    if (!clear) {  // near a tie, not finite: the reference's own division decides
+        KHG_UNROLL
+        for (int i = 0; i < NS; ++i) {
+            int qi;
+            if (!khg_quant_try(c[i], rd[i], &qi)) q[i] = khg_quant_divide(a, pl, c[i], band[i], x[i], y[i]);
         }
     }
+    uint32_t units = 0, seen = 0;
+    bool allhot = true;
+    KHG_UNROLL
+    for (int i = 0; i < NS; ++i) {
+        const uint32_t q1 = (uint32_t)(q[i] + 1);
+        const bool h = q1 <= 2u;
+        units += h ? khg_hot_unit(q1) : 0u;
+        seen |= h ? khg_hot_seen(q1, stream[i]) : 0u;
+        allhot = allhot && h;
+    }
+    const bool fresh = (seen & ~hot) != 0;
+    hot += units;
+    if (!allhot || fresh) {
+        KHG_UNROLL
+        for (int i = 0; i < NS; ++i)
+            q[i] = khg_count_rare<LHIST>(a, pl, lcnt, lfirst, hot, q[i], stream[i], (so + boff[i]) >> 1);
+    }
+    KHG_UNROLL
+    for (int i = 0; i < NS; ++i) *(int16_t*)((char*)pl.sym + (so + boff[i])) = (int16_t)q[i];
 }
 
 // First pair held by lane 0 of strip s of a plane with np pairs: two halo pairs before the strip's first output
@@ -274,33 +350,41 @@ KHG_DEV int khg_strip_first_pair(int s, int np)
 }
 
 // Finished, unscaled outputs (s2, d2) of row pair k of the lane's low-half column (L) and high-half column (H):
-// scale, store / quantise.  rd: this position's reciprocal divisors per band slot.
+// scale, store / quantise.  rd: this position's reciprocal divisors per band slot; so, llo: byte offsets of
+// position (k, pair) in the symbol plane and in the LL buffer.
 template <int LEVEL, int LHIST>
 KHG_DEV void khg_col_emit(const KhgFwdArgs& a, const KhgFwdPlane& pl, uint32_t* lcnt, uint32_t* lfirst, KhgHot& hot,
-                          int pair, int k, double s2L, double d2L, double s2H, double d2H, const double* rd)
+                          int pair, int k, double s2L, double d2L, double s2H, double d2H, const double* rd, uint32_t so,
+                          uint32_t llo)
 {
     const int hh = pl.ph / 2, hw = pl.pw / 2;
     const double loL = khg_fwd_scale_even(s2L), hiL = khg_fwd_scale_odd(d2L);
     const double loH = khg_fwd_scale_even(s2H), hiH = khg_fwd_scale_odd(d2H);
     if (pl.coef) {
-        pl.coef[(size_t)k * pl.coef_pitch + pair] = loL;
-        pl.coef[(size_t)k * pl.coef_pitch + hw + pair] = loH;
-        pl.coef[(size_t)(hh + k) * pl.coef_pitch + pair] = hiL;
-        pl.coef[(size_t)(hh + k) * pl.coef_pitch + hw + pair] = hiH;
+        const uint32_t c0 = (uint32_t)k * (uint32_t)pl.coef_pitch + (uint32_t)pair;
+        const uint32_t c1 = (uint32_t)(hh + k) * (uint32_t)pl.coef_pitch + (uint32_t)pair;
+        pl.coef[c0] = loL;
+        pl.coef[c0 + (uint32_t)hw] = loH;
+        pl.coef[c1] = hiL;
+        pl.coef[c1 + (uint32_t)hw] = hiH;
     }
     const bool emit = k >= pl.emit_k0 && k < pl.emit_k1;
+    const uint32_t right = 2u * (uint32_t)hw, down = 2u * (uint32_t)hh * (uint32_t)pl.sym_pitch;
     if (LEVEL == 1) {  // bands LH(4) HL(5) HH(6) are final, LL feeds level 2 (Compress.h:154-160)
-        pl.ll[(size_t)k * pl.ll_pitch + pair] = loL;
+        *(double*)((char*)pl.ll + llo) = loL;
         if (emit) {
-            khg_quant_store<LHIST>(a, pl, lcnt, lfirst, hot, loH, rd[0], 4, 0, k, hw + pair);
-            khg_quant_store<LHIST>(a, pl, lcnt, lfirst, hot, hiL, rd[1], 5, 1, hh + k, pair);
-            khg_quant_store<LHIST>(a, pl, lcnt, lfirst, hot, hiH, rd[2], 6, 1, hh + k, hw + pair);
+            const double c[3] = {loH, hiL, hiH};
+            const int band[3] = {4, 5, 6}, stream[3] = {0, 1, 1};
+            const int y[3] = {k, hh + k, hh + k}, x[3] = {hw + pair, pair, hw + pair};
+            const uint32_t boff[3] = {right, down, down + right};
+            khg_quant_emit<3, LHIST>(a, pl, lcnt, lfirst, hot, c, rd, band, stream, y, x, so, boff);
         }
     } else if (emit) {  // bands 0..3
-        khg_quant_store<LHIST>(a, pl, lcnt, lfirst, hot, loL, rd[0], 0, 0, k, pair);
-        khg_quant_store<LHIST>(a, pl, lcnt, lfirst, hot, loH, rd[1], 1, 0, k, hw + pair);
-        khg_quant_store<LHIST>(a, pl, lcnt, lfirst, hot, hiL, rd[2], 2, 1, hh + k, pair);
-        khg_quant_store<LHIST>(a, pl, lcnt, lfirst, hot, hiH, rd[3], 3, 1, hh + k, hw + pair);
+        const double c[4] = {loL, loH, hiL, hiH};
+        const int band[4] = {0, 1, 2, 3}, stream[4] = {0, 0, 1, 1};
+        const int y[4] = {k, k, hh + k, hh + k}, x[4] = {pair, hw + pair, pair, hw + pair};
+        const uint32_t boff[4] = {0, right, down, down + right};
+        khg_quant_emit<4, LHIST>(a, pl, lcnt, lfirst, hot, c, rd, band, stream, y, x, so, boff);
     }
 }
 
@@ -323,7 +407,9 @@ KHG_DEV void khg_fwd_wg_body(const KhgFwdArgs& a, const KhgFwdPlane* pls, int wg
     KhgHot hots[NP][KHG_NSLOT(256)];
     KhgFwdRaw<SRC> raws[KHG_NSLOT(256)];
     int pairs[KHG_NSLOT(256)];     // pair held by this lane
-    int flags[KHG_NSLOT(256)];     // bit 0: lane outputs its pair; bit 1: wave has a strip; bit 2: holds the plane's last pair
+    int flags[KHG_NSLOT(256)];     // bit 0: lane outputs its pair; bit 1: holds the plane's first pair; bit 2: its last
+    int edges[KHG_NSLOT(256)];     // wave-uniform: bit 1 / bit 2: a lane of this wave holds the first / last pair
+    uint32_t symo[KHG_NSLOT(256)], llo[KHG_NSLOT(256)];  // byte offsets of (k, pair) in the symbol plane / LL buffer
     // values of the row pass that cross an exchange: [row a / b][plane]
     double E[2][NP][KHG_NSLOT(256)], O[2][NP][KHG_NSLOT(256)], D1[2][NP][KHG_NSLOT(256)], S1[2][NP][KHG_NSLOT(256)],
         D2[2][NP][KHG_NSLOT(256)], X[2][NP][KHG_NSLOT(256)];
@@ -331,21 +417,25 @@ KHG_DEV void khg_fwd_wg_body(const KhgFwdArgs& a, const KhgFwdPlane* pls, int wg
     KHG_FOR_THREADS(256)
     {
         if (a.prof && tid == 0) khg_atomic_max64(&a.prof->prof_not_start, ~khg_clock());
-        const int lane = tid & 63, s = swg * KHG_WG_STRIPS + (tid >> 6);
+        const int lane = tid & 63, s = swg * KHG_WG_STRIPS + KHG_UNIFORM(tid >> 6);
         const int p0 = khg_strip_first_pair(s, np);
         const int p = p0 + lane;
         const int v0 = KHG_STRIP_PAIRS * s, v1 = v0 + KHG_STRIP_PAIRS < np ? v0 + KHG_STRIP_PAIRS : np;
         pairs[KHG_SLOT] = p < np ? p : np - 1;  // lanes beyond a narrow plane repeat its last pair (never output)
-        flags[KHG_SLOT] = (s < nstrips && p >= v0 && p < v1 ? 1 : 0) | (s < nstrips ? 2 : 0) | (p == np - 1 ? 4 : 0);
+        // a wave beyond the last strip repeats the last strip's loads and arithmetic without output
+        flags[KHG_SLOT] = (s < nstrips && p >= v0 && p < v1 ? 1 : 0) | (p == 0 ? 2 : 0) | (p == np - 1 ? 4 : 0);
+        edges[KHG_SLOT] = (p0 == 0 ? 2 : 0) | (p0 + KHG_LANES >= np ? 4 : 0);
+        // the first trip finishes row pair k0 - 4 (nothing is stored before k0; the offsets just run along)
+        symo[KHG_SLOT] = 2u * ((uint32_t)(k0 - 4) * (uint32_t)g.sym_pitch + (uint32_t)pairs[KHG_SLOT]);
+        llo[KHG_SLOT] = 8u * ((uint32_t)(k0 - 4) * (uint32_t)g.ll_pitch + (uint32_t)pairs[KHG_SLOT]);
         const KhgLift z = {0, 0, 0, 0, 0};
         for (int n = 0; n < NP; ++n) {
             colL[n][KHG_SLOT] = z;
             colH[n][KHG_SLOT] = z;
             hots[n][KHG_SLOT] = 0;
-            for (int rr = 0; rr < 2; ++rr) E[rr][n][KHG_SLOT] = O[rr][n][KHG_SLOT] = 0;  // waves without a strip
         }
-        if (flags[KHG_SLOT] & 2)  // rows of the first trip
-            khg_fwd_fetch<SRC>(a, g, raws[KHG_SLOT], khg_reflect(2 * (k0 - 2), g.ph), khg_reflect(2 * (k0 - 2) + 1, g.ph),
+        // rows of the first trip
+        khg_fwd_fetch<SRC>(a, g, raws[KHG_SLOT], khg_reflect(2 * (k0 - 2), g.ph), khg_reflect(2 * (k0 - 2) + 1, g.ph),
                                pairs[KHG_SLOT]);
         for (int n = 0; n < NP; ++n)
             for (int i = tid; i < SM::LHIST; i += 256) {
@@ -369,16 +459,16 @@ KHG_DEV void khg_fwd_wg_body(const KhgFwdArgs& a, const KhgFwdPlane* pls, int wg
     for (int j = k0 - 2; j <= k1 + 1; ++j) {
         KHG_FOR_THREADS(256)
         {
-            if (flags[KHG_SLOT] & 2) {
+            KHG_UNROLL
+            for (int rr = 0; rr < 2; ++rr)
                 KHG_UNROLL
-                for (int rr = 0; rr < 2; ++rr)
-                    KHG_UNROLL
-                    for (int n = 0; n < NP; ++n)
-                        khg_fwd_samples<SRC>(raws[KHG_SLOT], rr, n, E[rr][n][KHG_SLOT], O[rr][n][KHG_SLOT]);
-                if (j + 1 <= k1 + 1)  // next trip's rows: in flight during this trip's arithmetic
-                    khg_fwd_fetch<SRC>(a, g, raws[KHG_SLOT], khg_reflect(2 * (j + 1), g.ph),
-                                       khg_reflect(2 * (j + 1) + 1, g.ph), pairs[KHG_SLOT]);
-            }
+                for (int n = 0; n < NP; ++n)
+                    khg_fwd_samples<SRC>(raws[KHG_SLOT], rr, n, E[rr][n][KHG_SLOT], O[rr][n][KHG_SLOT]);
+            // next trip's rows: in flight during this trip's arithmetic (unconditional, also after the last
+            // trip, where the rows are reflected back into the plane and the loads are simply not used: a
+            // condition here would make the loads land in other registers and cost a wait and copies per trip)
+            khg_fwd_fetch<SRC>(a, g, raws[KHG_SLOT], khg_reflect(2 * (j + 1), g.ph), khg_reflect(2 * (j + 1) + 1, g.ph),
+                               pairs[KHG_SLOT]);
         }
         // predict 1: d1[p] = o[p] + P1 * (e[p] + e[p+1])
         for (int rr = 0; rr < 2; ++rr)
@@ -389,7 +479,10 @@ KHG_DEV void khg_fwd_wg_body(const KhgFwdArgs& a, const KhgFwdPlane* pls, int wg
             for (int rr = 0; rr < 2; ++rr)
                 KHG_UNROLL
                 for (int n = 0; n < NP; ++n) {
-                    const double en = (flags[KHG_SLOT] & 4) ? E[rr][n][KHG_SLOT] : X[rr][n][KHG_SLOT];
+                    double en = X[rr][n][KHG_SLOT];
+                    if (edges[KHG_SLOT] & 4) {  // DWT.h:18: x[n-1] += 2*a*x[n-2]
+                        if (flags[KHG_SLOT] & 4) en = E[rr][n][KHG_SLOT];
+                    }
                     D1[rr][n][KHG_SLOT] = O[rr][n][KHG_SLOT] + KHG_P1 * (E[rr][n][KHG_SLOT] + en);
                 }
         }
@@ -401,8 +494,13 @@ KHG_DEV void khg_fwd_wg_body(const KhgFwdArgs& a, const KhgFwdPlane* pls, int wg
             KHG_UNROLL
             for (int rr = 0; rr < 2; ++rr)
                 KHG_UNROLL
-                for (int n = 0; n < NP; ++n)
-                    S1[rr][n][KHG_SLOT] = E[rr][n][KHG_SLOT] + KHG_U1 * (X[rr][n][KHG_SLOT] + D1[rr][n][KHG_SLOT]);
+                for (int n = 0; n < NP; ++n) {
+                    double dp = X[rr][n][KHG_SLOT];
+                    if (edges[KHG_SLOT] & 2) {  // DWT.h:26: x[0] += 2*a*x[1]
+                        if (flags[KHG_SLOT] & 2) dp = D1[rr][n][KHG_SLOT];
+                    }
+                    S1[rr][n][KHG_SLOT] = E[rr][n][KHG_SLOT] + KHG_U1 * (dp + D1[rr][n][KHG_SLOT]);
+                }
         }
         // predict 2: d2[p] = d1[p] + P2 * (s1[p] + s1[p+1])
         for (int rr = 0; rr < 2; ++rr)
@@ -413,7 +511,10 @@ KHG_DEV void khg_fwd_wg_body(const KhgFwdArgs& a, const KhgFwdPlane* pls, int wg
             for (int rr = 0; rr < 2; ++rr)
                 KHG_UNROLL
                 for (int n = 0; n < NP; ++n) {
-                    const double sn = (flags[KHG_SLOT] & 4) ? S1[rr][n][KHG_SLOT] : X[rr][n][KHG_SLOT];
+                    double sn = X[rr][n][KHG_SLOT];
+                    if (edges[KHG_SLOT] & 4) {  // DWT.h:34
+                        if (flags[KHG_SLOT] & 4) sn = S1[rr][n][KHG_SLOT];
+                    }
                     D2[rr][n][KHG_SLOT] = D1[rr][n][KHG_SLOT] + KHG_P2 * (S1[rr][n][KHG_SLOT] + sn);
                 }
         }
@@ -435,7 +536,11 @@ KHG_DEV void khg_fwd_wg_body(const KhgFwdArgs& a, const KhgFwdPlane* pls, int wg
                 double lo[2], hi[2];
                 KHG_UNROLL
                 for (int rr = 0; rr < 2; ++rr) {
-                    const double s2 = S1[rr][n][KHG_SLOT] + KHG_U2 * (X[rr][n][KHG_SLOT] + D2[rr][n][KHG_SLOT]);
+                    double dp = X[rr][n][KHG_SLOT];
+                    if (edges[KHG_SLOT] & 2) {  // DWT.h:42
+                        if (flags[KHG_SLOT] & 2) dp = D2[rr][n][KHG_SLOT];
+                    }
+                    const double s2 = S1[rr][n][KHG_SLOT] + KHG_U2 * (dp + D2[rr][n][KHG_SLOT]);
                     lo[rr] = khg_fwd_scale_even(s2);
                     hi[rr] = khg_fwd_scale_odd(D2[rr][n][KHG_SLOT]);
                 }
@@ -444,8 +549,10 @@ KHG_DEV void khg_fwd_wg_body(const KhgFwdArgs& a, const KhgFwdPlane* pls, int wg
                 khg_fwd_step(colH[n][KHG_SLOT], hi[0], hi[1], s2H, d2H);
                 if (out)
                     khg_col_emit<LEVEL, SM::LHIST>(a, pls[n], sh.cnt[n], sh.first[n], hots[n][KHG_SLOT], pair, k, s2L, d2L,
-                                                   s2H, d2H, rdv);
+                                                   s2H, d2H, rdv, symo[KHG_SLOT], llo[KHG_SLOT]);
             }
+            symo[KHG_SLOT] += 2u * (uint32_t)g.sym_pitch;
+            llo[KHG_SLOT] += 8u * (uint32_t)g.ll_pitch;
         }
     }
 
