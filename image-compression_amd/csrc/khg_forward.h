@@ -176,23 +176,30 @@ struct KhgFwdRaw {
 KHG_DEV uint32_t khg_ld16(const uint8_t* p) { uint16_t v; __builtin_memcpy(&v, p, 2); return v; }
 KHG_DEV uint32_t khg_ld32(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
 
-// Rows ya, yb of the plane (already reflected into it), pair index p (already clamped into the plane).
+// Offset (in elements of the source) of plane row y's first sample: a wave-uniform number.
 template <int SRC>
-KHG_DEV void khg_fwd_fetch(const KhgFwdArgs& a, const KhgFwdPlane& pl, KhgFwdRaw<SRC>& raw, int ya, int yb, int p)
+KHG_DEV uint32_t khg_fwd_row_offset(const KhgFwdArgs& a, const KhgFwdPlane& pl, int y)
 {
-    // offsets are 32-bit (a plane has fewer than 2^31 samples): a scalar row offset plus the lane's column
+    if (SRC == KHG_SRC_PLANE) return (uint32_t)y * (uint32_t)pl.src_pitch;
+    // chroma site (y, x) reads the pixel at (2y, 2x): Colorspace.h:16-21
+    return (uint32_t)khg_band_row(a, SRC == KHG_SRC_Y ? y : 2 * y) * (uint32_t)a.img_w;
+}
+
+// Two rows of the plane at row offsets oa, ob (khg_fwd_row_offset); col = the lane's column offset in elements
+// (2 p for Y and planes, 4 p for chroma).  Offsets are 32-bit: a plane has fewer than 2^31 samples.
+template <int SRC>
+KHG_DEV void khg_fwd_fetch(const KhgFwdArgs& a, const KhgFwdPlane& pl, KhgFwdRaw<SRC>& raw, uint32_t oa, uint32_t ob,
+                           uint32_t col)
+{
+    oa += col;
+    ob += col;
     if constexpr (SRC == KHG_SRC_PLANE) {
-        __builtin_memcpy(&raw.w[0], pl.src + ((uint32_t)ya * (uint32_t)pl.src_pitch + 2u * (uint32_t)p), 16);
-        __builtin_memcpy(&raw.w[4], pl.src + ((uint32_t)yb * (uint32_t)pl.src_pitch + 2u * (uint32_t)p), 16);
+        __builtin_memcpy(&raw.w[0], pl.src + oa, 16);
+        __builtin_memcpy(&raw.w[4], pl.src + ob, 16);
     } else if constexpr (SRC == KHG_SRC_Y) {
-        const uint32_t oa = (uint32_t)khg_band_row(a, ya) * (uint32_t)a.img_w + 2u * (uint32_t)p;
-        const uint32_t ob = (uint32_t)khg_band_row(a, yb) * (uint32_t)a.img_w + 2u * (uint32_t)p;
         raw.w[0] = khg_ld16(a.r + oa); raw.w[1] = khg_ld16(a.g + oa); raw.w[2] = khg_ld16(a.b + oa);
         raw.w[3] = khg_ld16(a.r + ob); raw.w[4] = khg_ld16(a.g + ob); raw.w[5] = khg_ld16(a.b + ob);
     } else {
-        // chroma site (y, x) reads the pixel at (2y, 2x): Colorspace.h:16-21
-        const uint32_t oa = (uint32_t)khg_band_row(a, 2 * ya) * (uint32_t)a.img_w + 4u * (uint32_t)p;
-        const uint32_t ob = (uint32_t)khg_band_row(a, 2 * yb) * (uint32_t)a.img_w + 4u * (uint32_t)p;
         raw.w[0] = khg_ld32(a.r + oa); raw.w[1] = khg_ld32(a.g + oa); raw.w[2] = khg_ld32(a.b + oa);
         raw.w[3] = khg_ld32(a.r + ob); raw.w[4] = khg_ld32(a.g + ob); raw.w[5] = khg_ld32(a.b + ob);
     }
@@ -407,6 +414,7 @@ KHG_DEV void khg_fwd_wg_body(const KhgFwdArgs& a, const KhgFwdPlane* pls, int wg
     KhgHot hots[NP][KHG_NSLOT(256)];
     KhgFwdRaw<SRC> raws[KHG_NSLOT(256)];
     int pairs[KHG_NSLOT(256)];     // pair held by this lane
+    uint32_t cols[KHG_NSLOT(256)]; // its column offset in the source
     int flags[KHG_NSLOT(256)];     // bit 0: lane outputs its pair; bit 1: holds the plane's first pair; bit 2: its last
     int edges[KHG_NSLOT(256)];     // wave-uniform: bit 1 / bit 2: a lane of this wave holds the first / last pair
     uint32_t symo[KHG_NSLOT(256)], llo[KHG_NSLOT(256)];  // byte offsets of (k, pair) in the symbol plane / LL buffer
@@ -435,8 +443,9 @@ KHG_DEV void khg_fwd_wg_body(const KhgFwdArgs& a, const KhgFwdPlane* pls, int wg
             hots[n][KHG_SLOT] = 0;
         }
         // rows of the first trip
-        khg_fwd_fetch<SRC>(a, g, raws[KHG_SLOT], khg_reflect(2 * (k0 - 2), g.ph), khg_reflect(2 * (k0 - 2) + 1, g.ph),
-                               pairs[KHG_SLOT]);
+        cols[KHG_SLOT] = (SRC == KHG_SRC_C ? 4u : 2u) * (uint32_t)pairs[KHG_SLOT];
+        khg_fwd_fetch<SRC>(a, g, raws[KHG_SLOT], khg_fwd_row_offset<SRC>(a, g, khg_reflect(2 * (k0 - 2), g.ph)),
+                           khg_fwd_row_offset<SRC>(a, g, khg_reflect(2 * (k0 - 2) + 1, g.ph)), cols[KHG_SLOT]);
         for (int n = 0; n < NP; ++n)
             for (int i = tid; i < SM::LHIST; i += 256) {
                 sh.cnt[n][i] = 0;
@@ -457,6 +466,9 @@ KHG_DEV void khg_fwd_wg_body(const KhgFwdArgs& a, const KhgFwdPlane* pls, int wg
 
     // Row pairs k0-2 .. k1+1 are fed; the column pipeline hands back pair j-2 when pair j goes in.
     for (int j = k0 - 2; j <= k1 + 1; ++j) {
+        // source rows of the next trip (the same for every thread)
+        const uint32_t noa = KHG_UNIFORM(khg_fwd_row_offset<SRC>(a, g, khg_reflect(2 * (j + 1), g.ph)));
+        const uint32_t nob = KHG_UNIFORM(khg_fwd_row_offset<SRC>(a, g, khg_reflect(2 * (j + 1) + 1, g.ph)));
         KHG_FOR_THREADS(256)
         {
             KHG_UNROLL
@@ -467,8 +479,7 @@ KHG_DEV void khg_fwd_wg_body(const KhgFwdArgs& a, const KhgFwdPlane* pls, int wg
             // next trip's rows: in flight during this trip's arithmetic (unconditional, also after the last
             // trip, where the rows are reflected back into the plane and the loads are simply not used: a
             // condition here would make the loads land in other registers and cost a wait and copies per trip)
-            khg_fwd_fetch<SRC>(a, g, raws[KHG_SLOT], khg_reflect(2 * (j + 1), g.ph), khg_reflect(2 * (j + 1) + 1, g.ph),
-                               pairs[KHG_SLOT]);
+            khg_fwd_fetch<SRC>(a, g, raws[KHG_SLOT], noa, nob, cols[KHG_SLOT]);
         }
         // predict 1: d1[p] = o[p] + P1 * (e[p] + e[p+1])
         for (int rr = 0; rr < 2; ++rr)

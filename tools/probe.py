@@ -5,6 +5,9 @@ import time
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "image-compression_amd", "python"))
 import torch
+import khugle_amd.lib
+if os.environ.get("KHG_LIB"):  # an alternative build of the library (tools/gpu_variant.sh)
+    khugle_amd.lib.LIB_PATH = os.environ["KHG_LIB"]
 from khugle_amd import Codec
 
 H, W = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (4320, 7680)
