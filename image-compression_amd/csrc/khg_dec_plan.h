@@ -36,50 +36,62 @@ static inline KhgDecArgs khg_dec_args(const KhgWorkspace& ws, const KhgDecWorksp
     return d;
 }
 
-// Grid of one inverse-transform launch over a ph x pw plane.
-static inline KhgFwdGrid khg_inv_grid(int ph, int pw)
-{
-    return khg_strip_grid(ph, (pw + KHG_ISTRIP - 1) / KHG_ISTRIP, 1280, 8, 512);  // 5 workgroups per CU
-}
-
-// Inverse-transform arguments of colour component comp at level 2 (into the LL buffer) or
-// level 1 (into the component's f64 plane).
+// Plane of colour component comp at level 2 (into the LL buffer) or level 1 (into the component's f64 plane, or
+// dst when given) of an inverse launch, without its grid.
 // Tiles: every rank decodes the whole symbol planes, so a tile only restricts the rows it reconstructs: its band at
 // level 1, and at level 2 that band of the LL quadrant widened by 4 rows (level 1 reads two row pairs beyond).
-static inline KhgInvArgs khg_inv_args(const KhgWorkspace& ws, const KhgDecWorkspace& dws, int rows, int cols,
-                                      int comp, int level, KhgFwdGrid* grid, KhgTile tile = KhgTile{0, 1})
+static inline void khg_inv_plane(KhgInvPlane* pl, const KhgWorkspace& ws, const KhgDecWorkspace& dws, int rows, int cols,
+                                 int comp, int level, KhgTile tile, double* dst)
+{
+    memset(pl, 0, sizeof *pl);
+    const int prow = comp ? rows / 2 : rows, pcol = comp ? cols / 2 : cols;
+    pl->sym = ws.sym[comp];
+    pl->sym_pitch = pcol;
+    pl->ll = ws.ll[comp];
+    pl->ll_pitch = pcol / 2;
+    if (level == 2) {
+        pl->ph = prow / 2; pl->pw = pcol / 2;
+        pl->dst = ws.ll[comp];
+        pl->dst_pitch = pcol / 2;
+    } else {
+        pl->ph = prow; pl->pw = pcol;
+        pl->dst = dst ? dst : dws.plane[comp];  // unused for luma in the RGB variant
+        pl->dst_pitch = pcol;
+    }
+    for (int lvl = 0; lvl < 3; ++lvl) khg_make_quant(rows, cols, lvl, comp != 0, &pl->q[lvl]);
+    const int R0 = khg_tile_row0(prow, tile), R1 = khg_tile_row1(prow, tile);
+    if (level == 1) {
+        pl->row_begin = R0;
+        pl->row_end = R1;
+    } else {
+        pl->row_begin = R0 / 2 - 4 < 0 ? 0 : R0 / 2 - 4;
+        pl->row_end = R1 / 2 + 4 > pl->ph ? pl->ph : R1 / 2 + 4;
+        pl->row_begin &= ~1;
+        pl->row_end = (pl->row_end + 1) & ~1;
+    }
+}
+
+// An inverse launch over planes comp0 .. comp0 + n - 1 at `level` (KHG_INV_PLANES2 / KHG_INV_PLANES1), or the luma
+// plane into the RGB image (KHG_INV_RGB: n = 1, r / g / b set by the caller).  dst: optional outputs of the level-1
+// planes (null: the workspace's).
+static inline KhgInvArgs khg_inv_args(const KhgWorkspace& ws, const KhgDecWorkspace& dws, int rows, int cols, int comp0,
+                                      int n, int level, KhgTile tile = KhgTile{0, 1}, double* const dst[3] = nullptr)
 {
     KhgInvArgs a;
     memset(&a, 0, sizeof a);
-    const int prow = comp ? rows / 2 : rows, pcol = comp ? cols / 2 : cols;
-    a.sym = ws.sym[comp];
-    a.sym_pitch = pcol;
-    a.ll = ws.ll[comp];
-    a.ll_pitch = pcol / 2;
-    if (level == 2) {
-        a.ph = prow / 2; a.pw = pcol / 2;
-        a.dst = ws.ll[comp];
-        a.dst_pitch = pcol / 2;
-    } else {
-        a.ph = prow; a.pw = pcol;
-        a.dst = dws.plane[comp];  // null for luma: its level-1 pass writes RGB instead
-        a.dst_pitch = pcol;
-    }
+    a.hdr = dws.hdr;
     a.cb = dws.plane[1];
     a.cr = dws.plane[2];
-    a.hdr = dws.hdr;
-    for (int lvl = 0; lvl < 3; ++lvl) khg_make_quant(rows, cols, lvl, comp != 0, &a.q[lvl]);
-    const int R0 = khg_tile_row0(prow, tile), R1 = khg_tile_row1(prow, tile);
-    if (level == 1) {
-        a.row_begin = R0;
-        a.row_end = R1;
-    } else {
-        a.row_begin = R0 / 2 - 4 < 0 ? 0 : R0 / 2 - 4;
-        a.row_end = R1 / 2 + 4 > a.ph ? a.ph : R1 / 2 + 4;
-    }
     a.out_row0 = khg_tile_row0(rows, tile);
-    *grid = khg_inv_grid(a.row_end - a.row_begin, a.pw);
-    a.seg_rows = grid->seg_rows;
-    a.nstrip = grid->nstrip;
+    a.nplanes = n;
+    KhgGridGroup g[3];
+    for (int i = 0; i < n; ++i) {
+        khg_inv_plane(&a.pl[i], ws, dws, rows, cols, comp0 + i, level, tile, dst ? dst[comp0 + i] : nullptr);
+        g[i].pw = a.pl[i].pw; g[i].span = a.pl[i].row_end - a.pl[i].row_begin; g[i].weight = 1;
+    }
+    a.nwg = khg_plan_groups(g, n, KHG_FWD_SLOTS);
+    for (int i = 0; i < n; ++i) {
+        a.pl[i].seg_rows = g[i].seg_rows; a.pl[i].nseg = g[i].nseg; a.pl[i].nstrip_wg = g[i].nstrip_wg; a.pl[i].wg0 = g[i].wg0;
+    }
     return a;
 }

@@ -52,22 +52,19 @@ static int khg_decode_enqueue(khg_ctx* c, const uint8_t* d_comp, size_t len, int
     hipLaunchKernelGGL((khg_dec_map_kernel<KHG_MAXOFF>), dim3(grid_dec), dim3(256), 0, st, d);
     hipLaunchKernelGGL(khg_dec_chain_kernel, dim3(3), dim3(256), 0, st, d);
     hipLaunchKernelGGL(khg_dec_write_kernel, dim3(grid_dec), dim3(256), 0, st, d);
-    KhgFwdGrid gr;
-    for (int p = 0; p < 3; ++p) {  // Decompress.h:274-276
-        KhgInvArgs a = khg_inv_args(c->ws, c->dws, rows, cols, p, 2, &gr, tile);
-        hipLaunchKernelGGL((khg_inv_kernel<2, false>), dim3(gr.nstrip * gr.nseg), dim3(256), 0, st, a);
+    {  // Decompress.h:274-276: level 2 of the three components, one launch
+        const KhgInvArgs a = khg_inv_args(c->ws, c->dws, rows, cols, 0, 3, 2, tile);
+        hipLaunchKernelGGL((khg_inv_kernel<KHG_INV_PLANES2>), dim3(a.nwg), dim3(256), 0, st, a);
     }
-    for (int p = 2; p >= 0; --p) {  // Decompress.h:278-280; luma last: it also does Decompress.h:282 + Main.cpp:307-315
-        KhgInvArgs a = khg_inv_args(c->ws, c->dws, rows, cols, p, 1, &gr, tile);
-        if (ycbcr) {
-            a.dst = ycbcr[p];
-            hipLaunchKernelGGL((khg_inv_kernel<1, false>), dim3(gr.nstrip * gr.nseg), dim3(256), 0, st, a);
-        } else if (p == 0) {
-            a.r = d_r; a.g = d_g; a.b = d_b;
-            hipLaunchKernelGGL((khg_inv_kernel<1, true>), dim3(gr.nstrip * gr.nseg), dim3(256), 0, st, a);
-        } else {
-            hipLaunchKernelGGL((khg_inv_kernel<1, false>), dim3(gr.nstrip * gr.nseg), dim3(256), 0, st, a);
-        }
+    if (ycbcr) {  // Decompress.h:278-280 into the caller's f64 planes
+        const KhgInvArgs a = khg_inv_args(c->ws, c->dws, rows, cols, 0, 3, 1, tile, ycbcr);
+        hipLaunchKernelGGL((khg_inv_kernel<KHG_INV_PLANES1>), dim3(a.nwg), dim3(256), 0, st, a);
+    } else {  // Cb and Cr first; the luma launch also does Colorspace.h:25-36 + Main.cpp:307-315
+        const KhgInvArgs ac = khg_inv_args(c->ws, c->dws, rows, cols, 1, 2, 1, tile);
+        hipLaunchKernelGGL((khg_inv_kernel<KHG_INV_PLANES1>), dim3(ac.nwg), dim3(256), 0, st, ac);
+        KhgInvArgs ay = khg_inv_args(c->ws, c->dws, rows, cols, 0, 1, 1, tile);
+        ay.r = d_r; ay.g = d_g; ay.b = d_b;
+        hipLaunchKernelGGL((khg_inv_kernel<KHG_INV_RGB>), dim3(ay.nwg), dim3(256), 0, st, ay);
     }
     KHG_HIP(hipGetLastError());
     KHG_HIP(hipMemcpyAsync(c->h_res, c->ws.res, sizeof(KhgResult), hipMemcpyDeviceToHost, st));

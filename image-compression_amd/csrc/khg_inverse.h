@@ -1,73 +1,91 @@
 // khg_inverse.h -- dequantiser + one inverse 2-D CDF 9/7 lifting level, and the final
 // YCbCr -> RGB conversion.
 //
-// Mirror image of khg_forward.h (IWT2D runs columns first, then rows: DWT.h:143-165).
-// One workgroup walks down a strip of 240 output columns.  Per batch of 8 row pairs:
-//   columns: 248 threads each own one packed source column (124 low + 124 high, i.e. the
-//            strip's 120 + 120 plus a 2-pair halo each side); a thread reads its low/high
-//            coefficient pair (symbols are dequantised on the fly, Decompress.h:98-123),
-//            feeds the streaming inverse lifting pipeline in registers, and stores the two
-//            finished natural-order rows in LDS tile T
-//   rows   : each thread inverse-lifts a run of 16 outputs of one row from 12 low + 12 high
-//            values of T and writes them to the destination plane -- or, for the luma plane at level 1,
-//            converts them with the finished chroma planes to RGB (Colorspace.h:25-36) and writes the
-//            u8 image directly, so the f64 luma plane never exists in memory.
+// Mirror image of khg_forward.h, in the same lane-streaming layout (IWT2D runs columns first, then rows:
+// DWT.h:143-165).  A wave owns a strip of 64 pairs of output columns and walks down a segment of rows, one packed
+// row pair (low-pass row k, high-pass row hh+k) per trip; lane l holds pair p = first pair + l:
+//   columns: the lane's two packed source columns (low half p, high half hw+p) are read -- symbols dequantised on
+//            the fly (Decompress.h:98-123), the level-1 LL quadrant as f64 -- and fed to two streaming inverse
+//            lifting pipelines held in registers, which hand back two finished natural-order rows;
+//   rows   : each of the two rows is inverse-lifted across the lanes, the neighbouring pair's value coming from
+//            the neighbouring lane by a DPP wave shift (four exchanges per row, two halo pairs per strip side), and
+//            the lane's two samples are stored -- or, for the luma plane at level 1, combined with the finished
+//            chroma sample of this position (one Cb, one Cr per lane and trip: Colorspace.h:31-33 reads them at
+//            [y/2][x/2]) into RGB and written as u8, so the f64 luma plane never exists in memory.
 #pragma once
 #include "khg_common.h"
 #include "khg_decode.h"
+#include "khg_forward.h"
 
 enum {
-    KHG_ISTRIP = 240,
-    KHG_IHALF = KHG_ISTRIP / 2 + 4,   // 124 packed columns per half (2-pair halo each side)
-    KHG_ICOLS = 2 * KHG_IHALF,        // 248 column threads
-    KHG_T_PITCH = KHG_ICOLS + 1,
-    KHG_IBATCH = 8                    // row pairs per batch
+    KHG_DV_PAD = 4,
+    KHG_DV_N = KHG_WG_STRIPS * KHG_STRIP_PAIRS + 4 + KHG_MAX_SEG_ROWS / 2 + 2 * KHG_DV_PAD + 8  // divisors per band
 };
 
-struct KhgInvArgs {
+struct KhgInvPlane {
     const int16_t* sym;   // symbol plane of this colour component
     int sym_pitch;
     const double* ll;     // level 1: the LL quadrant (output of the level-2 inverse)
     int ll_pitch;
     int ph, pw;           // rows, cols of this transform
-    double* dst;          // natural-order output, ph x pw
+    double* dst;          // natural-order output, ph x pw (unused by the RGB variant)
     int dst_pitch;
-    const KhgDecHeader* hdr;  // supplies the preset (lvl) and the go/no-go flag
     int row_begin, row_end;  // output rows this launch produces (even; the whole plane, or one tile's band)
-    int out_row0;         // RGB variant: image row held by the first row of r/g/b (0 for a whole image)
     int seg_rows;         // output rows per workgroup segment (even)
-    int nstrip;
+    int nseg;
+    int nstrip_wg;        // workgroups side by side (KHG_WG_STRIPS strips each)
+    int wg0;              // first workgroup of this plane in the launch
     KhgQuant q[3];        // quantiser constants of this plane type for presets 0..2
+};
+
+struct KhgInvArgs {
+    const KhgDecHeader* hdr;  // supplies the preset (lvl) and the go/no-go flag
+    int nplanes;
+    int nwg;
+    int out_row0;             // RGB variant: image row held by the first row of r/g/b (0 for a whole image)
     // RGB variant (level 1 of the luma plane): the finished chroma planes and the output image
-    const double *cb, *cr;  // (ph/2) x (pw/2)
-    uint8_t *r, *g, *b;     // ph x pw, pitch pw
+    const double *cb, *cr;    // (ph/2) x (pw/2)
+    uint8_t *r, *g, *b;       // pitch pw
+    KhgInvPlane pl[3];
 };
 
+template <int LEVEL>
 struct KhgInvSmem {
-    double T[2 * KHG_IBATCH * KHG_T_PITCH];
+    enum { NBAND = LEVEL == 1 ? 3 : 4 };
+    double dv[NBAND * KHG_DV_N];  // divisor of band slot s at diagonal u: [s * KHG_DV_N + u]
+};
+union KhgInvSmemAny {
+    KhgInvSmem<1> l1;
+    KhgInvSmem<2> l2;
 };
 
-// State after feeding pair j: d_in[j], s1[j], d1[j-1], s0[j-1].
+// Streaming state of one 1-D inverse lifting line after feeding pair j: d[j], s1[j], d1[j-1], s0[j-1].
 struct KhgILift {
     double d, s1, d1, s0;
 };
 
-// Feed packed pair j = (low[j], high[j]); returns natural samples x[2(j-2)], x[2(j-2)+1].
 // With s[k] = low[k]/A, d[k] = high[k]*A (DWT.h:76-82, A = 1.149604398) the steps of DWT.h:84-114 read
 //   s1[k] = s[k]  + C1*(d[k-1]  + d[k])        undo update 2
 //   d1[k] = d[k]  + C2*(s1[k]   + s1[k+1])     undo predict 2
 //   s0[k] = s1[k] + C3*(d1[k-1] + d1[k])       undo update 1
 //   d0[k] = d1[k] + C4*(s0[k]   + s0[k+1])     undo predict 1
+#define KHG_IA (1.149604398)
+#define KHG_C1 (-0.4435068522)
+#define KHG_C2 (-0.8829110762)
+#define KHG_C3 (0.05298011854)
+#define KHG_C4 (1.586134342)
+
+KHG_DEV double khg_inv_unscale_low(double lo) { const double rA = 1 / KHG_IA; return khg_div_const(lo, KHG_IA, rA); }
+KHG_DEV double khg_inv_unscale_high(double hi) { return hi * KHG_IA; }
+
+// Feed packed pair j = (low[j], high[j]); returns natural samples x[2(j-2)], x[2(j-2)+1].
 KHG_DEV void khg_inv_step(KhgILift& st, double lo, double hi, double& xe, double& xo)
 {
-    const double A = 1.149604398;
-    const double C1 = -0.4435068522, C2 = -0.8829110762, C3 = 0.05298011854, C4 = 1.586134342;
-    const double rA = 1 / A;
-    double sn = khg_div_const(lo, A, rA), dn = hi * A;
-    double s1n = sn + C1 * (st.d + dn);
-    double d1n = st.d + C2 * (st.s1 + s1n);
-    double s0n = st.s1 + C3 * (st.d1 + d1n);
-    double d0 = st.d1 + C4 * (st.s0 + s0n);
+    double sn = khg_inv_unscale_low(lo), dn = khg_inv_unscale_high(hi);
+    double s1n = sn + KHG_C1 * (st.d + dn);
+    double d1n = st.d + KHG_C2 * (st.s1 + s1n);
+    double s0n = st.s1 + KHG_C3 * (st.d1 + d1n);
+    double d0 = st.d1 + KHG_C4 * (st.s0 + s0n);
     xe = st.s0;
     xo = d0;
     st.d = dn;
@@ -76,51 +94,26 @@ KHG_DEV void khg_inv_step(KhgILift& st, double lo, double hi, double& xe, double
     st.s0 = s0n;
 }
 
-// Raw inputs of one thread's column for one batch: symbols as stored, LL values as f64.  Fetched one batch
-// ahead (khg_inv_fetch) so the loads fly during the row phase, turned into coefficients when the column phase
-// consumes them (khg_inv_coef).
+// Raw inputs of one lane for one trip: the symbols at (ke, p), (ke, hw+p), (ko, p), (ko, hw+p) -- at level 1 the
+// first one is the LL sample instead -- and, in the RGB variant, the chroma sample of the rows the trip finishes.
 struct KhgInvRaw {
-    int q[2 * KHG_IBATCH];     // [2s] low-pass row of pair s, [2s+1] its high-pass row
-    double ll[KHG_IBATCH];     // level 1, low-pass row of a left-half column: the LL sample instead of a symbol
+    int q[4];
+    double ll, cb, cr;
 };
-
-// Band of packed position (yo, xo), -1 for the level-1 LL quadrant.
-template <int LEVEL>
-KHG_DEV int khg_inv_band(int yo, int xo, int hh, int hw)
-{
-    if (LEVEL == 2) return (yo >= hh ? 2 : 0) + (xo >= hw ? 1 : 0);
-    if (yo < hh && xo < hw) return -1;
-    return yo < hh ? 4 : (xo < hw ? 5 : 6);
-}
-
-template <int LEVEL>
-KHG_DEV void khg_inv_fetch(const KhgInvArgs& a, KhgInvRaw& raw, int s, int ye, int yo, int xo, int hh, int hw)
-{
-    if (khg_inv_band<LEVEL>(ye, xo, hh, hw) < 0) {
-        raw.ll[s] = a.ll[(size_t)ye * a.ll_pitch + xo];
-        raw.q[2 * s] = 0;
-    } else {
-        raw.ll[s] = 0.0;
-        raw.q[2 * s] = a.sym[(size_t)ye * a.sym_pitch + xo];
-    }
-    raw.q[2 * s + 1] = a.sym[(size_t)yo * a.sym_pitch + xo];
-}
-
-// Decompress.h:105, 120-121: coefficient = symbol * divisor of its band and position.
-template <int LEVEL>
-KHG_DEV double khg_inv_coef(const KhgQuant& qc, int lvl, int q, double ll, int y, int xo, int hh, int hw)
-{
-    const int band = khg_inv_band<LEVEL>(y, xo, hh, hw);
-    if (band < 0) return ll;
-    return (double)q * khg_divisor(qc, band, xo, y, lvl);
-}
 
 KHG_DEV uint32_t khg_clamp_u8(double v)
 {
     // Main.cpp:307-315: max(0, min(v, 255)) with the Win32 macros (a<b?a:b), (a>b?a:b), then truncation to
-    // unsigned char.  v is never NaN here (finite symbols times finite constants), and for every other v
-    // fmin/fmax pick the same operand as the macros, up to the sign of a zero that the truncation drops.
-    return (uint32_t)fmax(0.0, fmin(v, 255.0));
+    // unsigned char.  v is never NaN here (finite symbols times finite constants); the conversion to an unsigned
+    // integer truncates toward zero and saturates at zero, which is what clamping below does to every v < 1, and
+    // the integer minimum with 255 is what clamping above does to every v >= 255.
+#ifdef KHG_SIM
+    const double c = v < 0.0 ? 0.0 : (v > 4e9 ? 4e9 : v);
+    const uint32_t u = (uint32_t)c;
+#else
+    const uint32_t u = (uint32_t)v;  // v_cvt_u32_f64 saturates
+#endif
+    return u < 255u ? u : 255u;
 }
 
 // Colorspace.h:25-36 + Main.cpp:307-315 for the two pixels that share one chroma site: products and sums
@@ -128,175 +121,226 @@ KHG_DEV uint32_t khg_clamp_u8(double v)
 KHG_DEV void khg_rgb_pair(double y0, double y1, double Cb, double Cr, uint32_t rgb[3])
 {
     const double rr = Cr * 1.402, gb = Cb * -0.34414, gr = Cr * -0.71414, bb = Cb * 1.772;
-    rgb[0] = (uint32_t)khg_clamp_u8(y0 * 1 + rr) | ((uint32_t)khg_clamp_u8(y1 * 1 + rr) << 8);
-    rgb[1] = (uint32_t)khg_clamp_u8(y0 * 1 + gb + gr) | ((uint32_t)khg_clamp_u8(y1 * 1 + gb + gr) << 8);
-    rgb[2] = (uint32_t)khg_clamp_u8(y0 * 1 + bb) | ((uint32_t)khg_clamp_u8(y1 * 1 + bb) << 8);
+    rgb[0] = khg_clamp_u8(y0 * 1 + rr) | (khg_clamp_u8(y1 * 1 + rr) << 8);
+    rgb[1] = khg_clamp_u8(y0 * 1 + gb + gr) | (khg_clamp_u8(y1 * 1 + gb + gr) << 8);
+    rgb[2] = khg_clamp_u8(y0 * 1 + bb) | (khg_clamp_u8(y1 * 1 + bb) << 8);
 }
 
+KHG_DEV void khg_st16(uint8_t* p, uint32_t v) { const uint16_t h = (uint16_t)v; __builtin_memcpy(p, &h, 2); }
+
+// One workgroup: KHG_WG_STRIPS adjacent strips (one per wave) over one segment of output rows of plane pl.
 // RGB = true (level 1 of the luma plane only): the row phase does not store the luma samples but combines
 // them with the already reconstructed chroma planes and writes the u8 image.
-template <int LEVEL, bool RGB = false>
-KHG_DEV void khg_inv_strip_body(const KhgInvArgs& a, int bid, KhgInvSmem& sh)
+template <int LEVEL, bool RGB>
+KHG_DEV void khg_inv_wg_body(const KhgInvArgs& a, const KhgInvPlane& pl, int wgl, KhgInvSmem<LEVEL>& sh)
 {
-    const int strip = bid % a.nstrip, seg = bid / a.nstrip;
-    const int x0 = strip * KHG_ISTRIP;
-    const int r0 = a.row_begin + seg * a.seg_rows;
-    const int r1 = (r0 + a.seg_rows < a.row_end) ? r0 + a.seg_rows : a.row_end;
-    const int k0 = r0 / 2, k1 = r1 / 2;
-    const int nb = (k1 - k0 + 4 + KHG_IBATCH - 1) / KHG_IBATCH;
-    const int hh = a.ph / 2, hw = a.pw / 2;
+    typedef KhgInvSmem<LEVEL> SM;
     if (!a.hdr->ok) return;
     const int lvl = a.hdr->lvl;
-    const KhgQuant& qc = a.q[lvl];
+    const KhgQuant& qc = pl.q[lvl];
+    const int swg = wgl % pl.nstrip_wg, seg = wgl / pl.nstrip_wg;
+    const int np = pl.pw / 2, hh = pl.ph / 2, hw = pl.pw / 2;
+    const int nstrips = (np + KHG_STRIP_PAIRS - 1) / KHG_STRIP_PAIRS;
+    const int r0 = pl.row_begin + seg * pl.seg_rows;
+    const int r1 = (r0 + pl.seg_rows < pl.row_end) ? r0 + pl.seg_rows : pl.row_end;
+    const int k0 = r0 / 2, k1 = r1 / 2;
+    const int P0 = khg_strip_first_pair(swg * KHG_WG_STRIPS, np);  // first pair of the workgroup
+    // packed rows this segment reads (reflections included) lie in [klo, klo + nk)
+    const int klo = k0 - 4 < 0 ? 0 : k0 - 4;
+    const int khi = k1 + 3 > hh - 1 ? hh - 1 : k1 + 3;
 
-    // The RGB variant's row phase is register-hungry; holding a prefetched batch on top would cost it a wave
-    // per SIMD, which hurts more than the prefetch helps, so it loads at the start of the column phase.
-    const bool PREFETCH = !RGB;
-    KhgILift cs[KHG_NSLOT(256)];
+    KhgILift colL[KHG_NSLOT(256)], colH[KHG_NSLOT(256)];
     KhgInvRaw raws[KHG_NSLOT(256)];
-    uint32_t touch[KHG_NSLOT(256)] = {0};  // see KHG_TOUCH
+    int pairs[KHG_NSLOT(256)];
+    int flags[KHG_NSLOT(256)];  // bit 0: lane outputs its pair; bit 1: holds the plane's first pair; bit 2: its last
+    int edges[KHG_NSLOT(256)];  // wave-uniform: bit 1 / bit 2: a lane of this wave holds the first / last pair
+    double LO[2][KHG_NSLOT(256)], HI[2][KHG_NSLOT(256)], S1[2][KHG_NSLOT(256)], D1[2][KHG_NSLOT(256)],
+        S0[2][KHG_NSLOT(256)], X[2][KHG_NSLOT(256)], CB[KHG_NSLOT(256)], CR[KHG_NSLOT(256)];
+
+    // Packed row indices of trip j: low-pass row ke, high-pass row ko (whole-sample reflection of the natural rows
+    // 2j and 2j+1 at the plane's top and bottom).
+#define KHG_INV_KE(j) (khg_reflect(2 * (j), pl.ph) >> 1)
+#define KHG_INV_KO(j) (khg_reflect(2 * (j) + 1, pl.ph) >> 1)
+
     KHG_FOR_THREADS(256)
     {
-        KhgILift z = {0, 0, 0, 0};
-        cs[KHG_SLOT] = z;
-        if (PREFETCH && tid < KHG_ICOLS) {  // inputs of the first batch
-            const int half = tid >= KHG_IHALF, tt = half ? tid - KHG_IHALF : tid;
-            const int rx = khg_reflect(2 * ((x0 >> 1) - 2 + tt) + half, a.pw);
-            const int xo = (rx >> 1) + (half ? hw : 0);
-            KHG_UNROLL
-            for (int s = 0; s < KHG_IBATCH; ++s) {
-                int j = k0 - 2 + s;
-                khg_inv_fetch<LEVEL>(a, raws[KHG_SLOT], s, khg_reflect(2 * j, a.ph) >> 1,
-                                     hh + (khg_reflect(2 * j + 1, a.ph) >> 1), xo, hh, hw);
-            }
+        const int lane = tid & 63, s = swg * KHG_WG_STRIPS + KHG_UNIFORM(tid >> 6);
+        const int p0 = khg_strip_first_pair(s, np);
+        const int p = p0 + lane;
+        const int v0 = KHG_STRIP_PAIRS * s, v1 = v0 + KHG_STRIP_PAIRS < np ? v0 + KHG_STRIP_PAIRS : np;
+        pairs[KHG_SLOT] = p < np ? p : np - 1;
+        flags[KHG_SLOT] = (s < nstrips && p >= v0 && p < v1 ? 1 : 0) | (p == 0 ? 2 : 0) | (p == np - 1 ? 4 : 0);
+        edges[KHG_SLOT] = (p0 == 0 ? 2 : 0) | (p0 + KHG_LANES >= np ? 4 : 0);
+        const KhgILift z = {0, 0, 0, 0};
+        colL[KHG_SLOT] = z;
+        colH[KHG_SLOT] = z;
+        // Decompress.h:105, 120-121: coefficient = symbol * divisor of its band and position; the divisor depends on
+        // the band and on x + y only: pair P0 + i at packed row klo + r sits on diagonal u = i + r.
+        const int nu = KHG_WG_STRIPS * KHG_STRIP_PAIRS + 4 + (khi - klo + 1);
+        for (int e = tid; e < SM::NBAND * nu; e += 256) {
+            int s2 = e / nu, u = e - s2 * nu;
+            int band = LEVEL == 1 ? 4 + s2 : s2;
+            int by = (LEVEL == 1 ? (band >= 5) : (band >= 2)) ? hh : 0;
+            int bx = (LEVEL == 1 ? (band != 5) : (band & 1)) ? hw : 0;
+            sh.dv[s2 * KHG_DV_N + u] = khg_divisor(qc, band, bx + P0 + u, by + klo, lvl);
         }
     }
-    for (int b = 0; b < nb; ++b) {
+    KHG_BARRIER();
+
+    // Loads of trip j into raw (all four positions, and the chroma sample of the rows trip j finishes).
+#define KHG_INV_FETCH(raw, j)                                                                               \
+    {                                                                                                       \
+        const int ke_ = KHG_INV_KE(j), ko_ = hh + KHG_INV_KO(j);                                            \
+        const uint32_t oe_ = (uint32_t)ke_ * (uint32_t)pl.sym_pitch + (uint32_t)pairs[KHG_SLOT];            \
+        const uint32_t oo_ = (uint32_t)ko_ * (uint32_t)pl.sym_pitch + (uint32_t)pairs[KHG_SLOT];            \
+        if (LEVEL == 1) {                                                                                   \
+            (raw).ll = pl.ll[(uint32_t)ke_ * (uint32_t)pl.ll_pitch + (uint32_t)pairs[KHG_SLOT]];            \
+            (raw).q[0] = 0;                                                                                 \
+        } else {                                                                                            \
+            (raw).ll = 0.0;                                                                                 \
+            (raw).q[0] = pl.sym[oe_];                                                                       \
+        }                                                                                                   \
+        (raw).q[1] = pl.sym[oe_ + (uint32_t)hw];                                                            \
+        (raw).q[2] = pl.sym[oo_];                                                                           \
+        (raw).q[3] = pl.sym[oo_ + (uint32_t)hw];                                                            \
+        if (RGB) {                                                                                          \
+            int m_ = (j) - 2;                                                                               \
+            m_ = m_ < 0 ? 0 : (m_ > hh - 1 ? hh - 1 : m_);                                                  \
+            const uint32_t oc_ = (uint32_t)m_ * (uint32_t)hw + (uint32_t)pairs[KHG_SLOT];                   \
+            (raw).cb = a.cb[oc_];                                                                           \
+            (raw).cr = a.cr[oc_];                                                                           \
+        }                                                                                                   \
+    }
+
+    KHG_FOR_THREADS(256) { KHG_INV_FETCH(raws[KHG_SLOT], k0 - 2) }
+
+    for (int j = k0 - 2; j <= k1 + 1; ++j) {
         KHG_FOR_THREADS(256)
         {
-            if (tid < KHG_ICOLS) {
-                // ---- column phase: packed source column of this thread
-                const int half = tid >= KHG_IHALF, tt = half ? tid - KHG_IHALF : tid;
-                const int rx = khg_reflect(2 * ((x0 >> 1) - 2 + tt) + half, a.pw);  // natural column, parity = half
-                const int xo = (rx >> 1) + (half ? hw : 0);
-                KhgILift st = cs[KHG_SLOT];
-                KhgInvRaw& raw = raws[KHG_SLOT];
-                if (!PREFETCH) {  // all loads of the batch first (independent), then the lifting chain
-                    KHG_UNROLL
-                    for (int s = 0; s < KHG_IBATCH; ++s) {
-                        int j = k0 - 2 + b * KHG_IBATCH + s;
-                        khg_inv_fetch<LEVEL>(a, raw, s, khg_reflect(2 * j, a.ph) >> 1,
-                                             hh + (khg_reflect(2 * j + 1, a.ph) >> 1), xo, hh, hw);
-                    }
-                }
-                KHG_UNROLL
-                for (int s = 0; s < KHG_IBATCH; ++s) {
-                    int j = k0 - 2 + b * KHG_IBATCH + s;  // row pair fed in this step
-                    int ye = khg_reflect(2 * j, a.ph) >> 1;
-                    int yo = hh + (khg_reflect(2 * j + 1, a.ph) >> 1);
-                    double lo = khg_inv_coef<LEVEL>(qc, lvl, raw.q[2 * s], raw.ll[s], ye, xo, hh, hw);
-                    double hi = khg_inv_coef<LEVEL>(qc, lvl, raw.q[2 * s + 1], 0.0, yo, xo, hh, hw);
-                    double xe, xod;
-                    khg_inv_step(st, lo, hi, xe, xod);
-                    sh.T[(2 * s) * KHG_T_PITCH + tid] = xe;
-                    sh.T[(2 * s + 1) * KHG_T_PITCH + tid] = xod;
-                }
-                cs[KHG_SLOT] = st;
-                if (!PREFETCH && b + 1 < nb) {
-                    // No registers to hold the next batch in: at least bring its lines closer.  A wave's 64
-                    // columns span two 128-byte lines of a symbol row and five 64-byte pieces of an LL row; lane l
-                    // touches row slot l % 16 (symbols; first and last 16 lanes) or LL row l % 8 (every lane), each
-                    // at its own column.
-                    const int l = tid & 63;
-                    const int jn = k0 - 2 + (b + 1) * KHG_IBATCH;
-                    const bool llrows = khg_inv_band<LEVEL>(0, xo, hh, hw) < 0;  // low-pass rows come from the LL plane
-                    if (llrows) {
-                        const int ye = khg_reflect(2 * (jn + (l & 7)), a.ph) >> 1;
-                        KHG_TOUCH(touch[KHG_SLOT], a.ll + (size_t)ye * a.ll_pitch + xo);
-                    }
-                    if (l < 16 || l >= 48) {
-                        const int slot = l & 15, j = jn + (slot >> 1);
-                        const int row = (slot & 1) ? hh + (khg_reflect(2 * j + 1, a.ph) >> 1) : khg_reflect(2 * j, a.ph) >> 1;
-                        if ((slot & 1) || !llrows) KHG_TOUCH(touch[KHG_SLOT], a.sym + (size_t)row * a.sym_pitch + xo);
-                    }
-                }
-                if (PREFETCH && b + 1 < nb) {  // next batch's inputs: in flight during the row phase
-                    KHG_UNROLL
-                    for (int s = 0; s < KHG_IBATCH; ++s) {
-                        int j = k0 - 2 + (b + 1) * KHG_IBATCH + s;
-                        khg_inv_fetch<LEVEL>(a, raw, s, khg_reflect(2 * j, a.ph) >> 1,
-                                             hh + (khg_reflect(2 * j + 1, a.ph) >> 1), xo, hh, hw);
-                    }
-                }
+            // ---- column phase: dequantise, feed the two column pipelines, get natural rows 2(j-2), 2(j-2)+1
+            const KhgInvRaw raw = raws[KHG_SLOT];
+            const int ke = KHG_INV_KE(j), ko = KHG_INV_KO(j);
+            const int ue = (pairs[KHG_SLOT] - P0) + (ke - klo), uo = (pairs[KHG_SLOT] - P0) + (ko - klo);
+            double c[4];
+            if (LEVEL == 1) {
+                c[0] = raw.ll;
+                c[1] = (double)raw.q[1] * sh.dv[0 * KHG_DV_N + ue];  // band 4: (ke, hw + p)
+                c[2] = (double)raw.q[2] * sh.dv[1 * KHG_DV_N + uo];  // band 5: (hh + ko, p)
+                c[3] = (double)raw.q[3] * sh.dv[2 * KHG_DV_N + uo];  // band 6: (hh + ko, hw + p)
+            } else {
+                c[0] = (double)raw.q[0] * sh.dv[0 * KHG_DV_N + ue];
+                c[1] = (double)raw.q[1] * sh.dv[1 * KHG_DV_N + ue];
+                c[2] = (double)raw.q[2] * sh.dv[2 * KHG_DV_N + uo];
+                c[3] = (double)raw.q[3] * sh.dv[3 * KHG_DV_N + uo];
+            }
+            // next trip's inputs: in flight during this trip's arithmetic (unconditional: after the last trip the
+            // rows are reflected back into the plane and the loads are not used)
+            KHG_INV_FETCH(raws[KHG_SLOT], j + 1)
+            khg_inv_step(colL[KHG_SLOT], c[0], c[2], LO[0][KHG_SLOT], LO[1][KHG_SLOT]);
+            khg_inv_step(colH[KHG_SLOT], c[1], c[3], HI[0][KHG_SLOT], HI[1][KHG_SLOT]);
+            // ---- row phase on the two rows: s = low / A, d = high * A
+            KHG_UNROLL
+            for (int rr = 0; rr < 2; ++rr) {
+                LO[rr][KHG_SLOT] = khg_inv_unscale_low(LO[rr][KHG_SLOT]);
+                HI[rr][KHG_SLOT] = khg_inv_unscale_high(HI[rr][KHG_SLOT]);
+            }
+            if (RGB) {  // this trip's chroma sample (raws now holds the next trip's)
+                CB[KHG_SLOT] = raw.cb;
+                CR[KHG_SLOT] = raw.cr;
             }
         }
-        KHG_BARRIER();
+        // s1[p] = s[p] + C1 * (d[p-1] + d[p])
+        for (int rr = 0; rr < 2; ++rr) KHG_LANE_PREV(X[rr], HI[rr])
         KHG_FOR_THREADS(256)
         {
-            // ---- row phase: natural row of T, outputs [16*run, 16*run+16) of the strip
-            const int rr = tid & 15, run = tid >> 4;
-            const int pair = k0 - 4 + b * KHG_IBATCH + (rr >> 1);  // column phase step s emitted pair j-2
-            const int gy = 2 * pair + (rr & 1);
-            const int gx0 = x0 + run * 16;
-            if (run < KHG_ISTRIP / 16 && pair >= k0 && pair < k1 && gx0 < a.pw) {
-                const double* lo = &sh.T[rr * KHG_T_PITCH + run * 8];
-                const double* hi = lo + KHG_IHALF;
-                double* out = RGB ? nullptr : a.dst + (size_t)gy * a.dst_pitch + gx0;
-                const int nv = a.pw - gx0 >= 16 ? 16 : a.pw - gx0;  // 8 or 16 outputs are inside (pw = 0 mod 8)
-                double cbv[8], crv[8], yv[16];
-                if (RGB) {  // issued first: in flight during the lifting below
-                    const size_t cpos = (size_t)(gy >> 1) * (a.pw >> 1) + (gx0 >> 1);
-                    if (nv == 16) {  // 64 contiguous, 64-byte aligned bytes per plane: four 16-byte loads each
-                        __builtin_memcpy(cbv, a.cb + cpos, 64);
-                        __builtin_memcpy(crv, a.cr + cpos, 64);
-                    } else {
-                        KHG_UNROLL
-                        for (int c = 0; c < 8; ++c) {
-                            cbv[c] = 2 * c < nv ? a.cb[cpos + c] : 0.0;
-                            crv[c] = 2 * c < nv ? a.cr[cpos + c] : 0.0;
-                        }
-                    }
+            KHG_UNROLL
+            for (int rr = 0; rr < 2; ++rr) {
+                double dp = X[rr][KHG_SLOT];
+                if (edges[KHG_SLOT] & 2) {
+                    if (flags[KHG_SLOT] & 2) dp = HI[rr][KHG_SLOT];
                 }
-                KhgILift st = {0, 0, 0, 0};
+                S1[rr][KHG_SLOT] = LO[rr][KHG_SLOT] + KHG_C1 * (dp + HI[rr][KHG_SLOT]);
+            }
+        }
+        // d1[p] = d[p] + C2 * (s1[p] + s1[p+1])
+        for (int rr = 0; rr < 2; ++rr) KHG_LANE_NEXT(X[rr], S1[rr])
+        KHG_FOR_THREADS(256)
+        {
+            KHG_UNROLL
+            for (int rr = 0; rr < 2; ++rr) {
+                double sn = X[rr][KHG_SLOT];
+                if (edges[KHG_SLOT] & 4) {
+                    if (flags[KHG_SLOT] & 4) sn = S1[rr][KHG_SLOT];
+                }
+                D1[rr][KHG_SLOT] = HI[rr][KHG_SLOT] + KHG_C2 * (S1[rr][KHG_SLOT] + sn);
+            }
+        }
+        // s0[p] = s1[p] + C3 * (d1[p-1] + d1[p])
+        for (int rr = 0; rr < 2; ++rr) KHG_LANE_PREV(X[rr], D1[rr])
+        KHG_FOR_THREADS(256)
+        {
+            KHG_UNROLL
+            for (int rr = 0; rr < 2; ++rr) {
+                double dp = X[rr][KHG_SLOT];
+                if (edges[KHG_SLOT] & 2) {
+                    if (flags[KHG_SLOT] & 2) dp = D1[rr][KHG_SLOT];
+                }
+                S0[rr][KHG_SLOT] = S1[rr][KHG_SLOT] + KHG_C3 * (dp + D1[rr][KHG_SLOT]);
+            }
+        }
+        // d0[p] = d1[p] + C4 * (s0[p] + s0[p+1]); x[2p] = s0[p], x[2p+1] = d0[p]
+        for (int rr = 0; rr < 2; ++rr) KHG_LANE_NEXT(X[rr], S0[rr])
+        KHG_FOR_THREADS(256)
+        {
+            const int m = j - 2;  // finished row pair
+            if ((flags[KHG_SLOT] & 1) && m >= k0 && m < k1) {
+                const int pair = pairs[KHG_SLOT];
+                double xe[2], xo[2];
                 KHG_UNROLL
-                for (int i = 0; i < 12; ++i) {
-                    double xe, xod;
-                    khg_inv_step(st, lo[i], hi[i], xe, xod);
-                    if (RGB) {
-                        if (i >= 4) {
-                            yv[2 * (i - 4)] = xe;
-                            yv[2 * (i - 4) + 1] = xod;
-                        }
-                    } else if (i >= 4 && 2 * (i - 4) < nv) {  // pw is even: a pair never straddles the edge
-                        out[2 * (i - 4)] = xe;
-                        out[2 * (i - 4) + 1] = xod;
+                for (int rr = 0; rr < 2; ++rr) {
+                    double sn = X[rr][KHG_SLOT];
+                    if (edges[KHG_SLOT] & 4) {
+                        if (flags[KHG_SLOT] & 4) sn = S0[rr][KHG_SLOT];
                     }
+                    xe[rr] = S0[rr][KHG_SLOT];
+                    xo[rr] = D1[rr][KHG_SLOT] + KHG_C4 * (S0[rr][KHG_SLOT] + sn);
                 }
                 if (RGB) {
-                    uint64_t pk[3][2] = {{0, 0}, {0, 0}, {0, 0}};  // 8 pixels per 64-bit word, first pixel lowest
                     KHG_UNROLL
-                    for (int c = 0; c < 8; ++c) {
+                    for (int rr = 0; rr < 2; ++rr) {
                         uint32_t rgb[3];
-                        khg_rgb_pair(yv[2 * c], yv[2 * c + 1], cbv[c], crv[c], rgb);
-                        for (int ch = 0; ch < 3; ++ch) pk[ch][c >> 2] |= (uint64_t)rgb[ch] << (16 * (c & 3));
+                        khg_rgb_pair(xe[rr], xo[rr], CB[KHG_SLOT], CR[KHG_SLOT], rgb);
+                        const uint32_t o = (uint32_t)(2 * m + rr - a.out_row0) * (uint32_t)pl.pw + 2u * (uint32_t)pair;
+                        khg_st16(a.r + o, rgb[0]);
+                        khg_st16(a.g + o, rgb[1]);
+                        khg_st16(a.b + o, rgb[2]);
                     }
-                    const size_t p = (size_t)(gy - a.out_row0) * a.pw + gx0;
-                    if (nv == 16) {  // one 16-byte store per plane
-                        __builtin_memcpy(a.r + p, pk[0], 16);
-                        __builtin_memcpy(a.g + p, pk[1], 16);
-                        __builtin_memcpy(a.b + p, pk[2], 16);
-                    } else {
-                        __builtin_memcpy(a.r + p, pk[0], 8);
-                        __builtin_memcpy(a.g + p, pk[1], 8);
-                        __builtin_memcpy(a.b + p, pk[2], 8);
+                } else {
+                    KHG_UNROLL
+                    for (int rr = 0; rr < 2; ++rr) {
+                        double* out = pl.dst + ((uint32_t)(2 * m + rr) * (uint32_t)pl.dst_pitch + 2u * (uint32_t)pair);
+                        const double v[2] = {xe[rr], xo[rr]};
+                        __builtin_memcpy(out, v, 16);
                     }
                 }
             }
         }
-        KHG_BARRIER();
     }
-    if (!PREFETCH) {
-        KHG_FOR_THREADS(256) { KHG_TOUCH_DONE(touch[KHG_SLOT]); }
-    }
+#undef KHG_INV_FETCH
+#undef KHG_INV_KE
+#undef KHG_INV_KO
 }
 
+// Launch kinds: level 2 of the three components into their LL buffers; level 1 of planes into f64 planes (Cb and
+// Cr, or all three for the plane outputs of DecompressImage); level 1 of the luma plane into the RGB image.
+enum { KHG_INV_PLANES2 = 0, KHG_INV_PLANES1 = 1, KHG_INV_RGB = 2 };
+
+template <int KIND>
+KHG_DEV void khg_inv_launch_body(const KhgInvArgs& a, int wg, KhgInvSmemAny& sh)
+{
+    int p = 0;
+    while (p + 1 < a.nplanes && wg >= a.pl[p + 1].wg0) ++p;
+    if constexpr (KIND == KHG_INV_PLANES2) khg_inv_wg_body<2, false>(a, a.pl[p], wg - a.pl[p].wg0, sh.l2);
+    else if constexpr (KIND == KHG_INV_PLANES1) khg_inv_wg_body<1, false>(a, a.pl[p], wg - a.pl[p].wg0, sh.l1);
+    else khg_inv_wg_body<1, true>(a, a.pl[p], wg - a.pl[p].wg0, sh.l1);
+}

@@ -204,33 +204,37 @@ static inline void khg_fwd_plane(KhgFwdPlane* pl, const KhgWorkspace& ws, int ro
     }
 }
 
-// Workgroups of the chip that a forward launch is planned for: 4 per CU (4 waves per SIMD) on 256 CUs.
+// Workgroups of the chip that a transform launch is planned for: 4 per CU (4 waves per SIMD) on 256 CUs.
 #ifndef KHG_FWD_SLOTS
 #define KHG_FWD_SLOTS 1024
 #endif
 
-// Grid of a forward launch: ngroup groups of planes (a group shares one grid: Y alone, Cb with Cr), group i
-// starting at plane first[i] and costing weight[i] per row relative to a single plane.  A workgroup walks a segment
-// of its rows plus 8 warm-up rows, so segments should be as tall as the chip allows: the segment heights are the
-// ones at which every group's workgroups carry about the same work and all of them together just fit the chip at
-// once (KHG_FWD_SLOTS), within 16 .. KHG_MAX_SEG_ROWS rows.
-static inline void khg_fwd_plan_grid(KhgFwdArgs* a, int ngroup, const int* first, const int* count, const int* weight)
+// One group of planes of a transform launch that share a grid (Y alone, Cb with Cr, ...): pw columns, `span` rows
+// to transform, `weight` = cost per row relative to a single plane.  The planner fills in the rest.
+struct KhgGridGroup {
+    int pw, span, weight;
+    int seg_rows, nseg, nstrip_wg, wg0;
+};
+
+// Grid of a transform launch.  A workgroup walks a segment of its rows plus 8 warm-up rows, so segments should be as
+// tall as the chip allows: the segment heights are the ones at which every group's workgroups carry about the same
+// work and all of them together just fit the chip at once (`slots`), within 16 .. KHG_MAX_SEG_ROWS rows.
+// Returns the number of workgroups.
+static inline int khg_plan_groups(KhgGridGroup* g, int ngroup, int slots)
 {
     long total = 0;
     for (int i = 0; i < ngroup; ++i) {
-        KhgFwdPlane& pl = a->pl[first[i]];
-        const int nstrips = (pl.pw / 2 + KHG_STRIP_PAIRS - 1) / KHG_STRIP_PAIRS;
-        pl.nstrip_wg = (nstrips + KHG_WG_STRIPS - 1) / KHG_WG_STRIPS;
-        total += (long)pl.nstrip_wg * (pl.row_end - pl.row_begin) * weight[i];
+        const int nstrips = (g[i].pw / 2 + KHG_STRIP_PAIRS - 1) / KHG_STRIP_PAIRS;
+        g[i].nstrip_wg = (nstrips + KHG_WG_STRIPS - 1) / KHG_WG_STRIPS;
+        total += (long)g[i].nstrip_wg * g[i].span * g[i].weight;
     }
-    long T = (total + KHG_FWD_SLOTS - 1) / KHG_FWD_SLOTS;  // weighted rows per workgroup
+    long T = (total + slots - 1) / slots;  // weighted rows per workgroup
     for (;;) {
         long wgs = 0;
         bool all_max = true;
         for (int i = 0; i < ngroup; ++i) {
-            KhgFwdPlane& pl = a->pl[first[i]];
-            const int span = pl.row_end - pl.row_begin;
-            int seg = (int)((T / weight[i] + 1) & ~1L);
+            const int span = g[i].span;
+            int seg = (int)((T / g[i].weight + 1) & ~1L);
             if (seg < 16) seg = 16;
             if (seg > KHG_MAX_SEG_ROWS) seg = KHG_MAX_SEG_ROWS;
             if (seg > span) seg = span;
@@ -238,24 +242,35 @@ static inline void khg_fwd_plan_grid(KhgFwdArgs* a, int ngroup, const int* first
             int nseg = (span + seg - 1) / seg;
             seg = ((span + nseg - 1) / nseg + 1) & ~1;  // equal segments
             nseg = (span + seg - 1) / seg;
-            pl.seg_rows = seg;
-            pl.nseg = nseg;
-            wgs += (long)pl.nstrip_wg * nseg;
+            g[i].seg_rows = seg;
+            g[i].nseg = nseg;
+            wgs += (long)g[i].nstrip_wg * nseg;
         }
-        if (wgs <= KHG_FWD_SLOTS || all_max || T > 4L * KHG_MAX_SEG_ROWS) break;
+        if (wgs <= slots || all_max || T > 4L * KHG_MAX_SEG_ROWS) break;
         T += 2;
     }
     int wg = 0;
     for (int i = 0; i < ngroup; ++i) {
-        KhgFwdPlane& pl = a->pl[first[i]];
-        pl.wg0 = wg;
-        for (int j = 1; j < count[i]; ++j) {  // the group's other planes share the grid
-            KhgFwdPlane& o = a->pl[first[i] + j];
-            o.seg_rows = pl.seg_rows; o.nseg = pl.nseg; o.nstrip_wg = pl.nstrip_wg; o.wg0 = wg;
-        }
-        wg += pl.nstrip_wg * pl.nseg;
+        g[i].wg0 = wg;
+        wg += g[i].nstrip_wg * g[i].nseg;
     }
-    a->nwg = wg;
+    return wg;
+}
+
+// Grid of a forward launch: group i starts at plane first[i] and holds count[i] planes.
+static inline void khg_fwd_plan_grid(KhgFwdArgs* a, int ngroup, const int* first, const int* count, const int* weight)
+{
+    KhgGridGroup g[3];
+    for (int i = 0; i < ngroup; ++i) {
+        const KhgFwdPlane& pl = a->pl[first[i]];
+        g[i].pw = pl.pw; g[i].span = pl.row_end - pl.row_begin; g[i].weight = weight[i];
+    }
+    a->nwg = khg_plan_groups(g, ngroup, KHG_FWD_SLOTS);
+    for (int i = 0; i < ngroup; ++i)
+        for (int j = 0; j < count[i]; ++j) {
+            KhgFwdPlane& o = a->pl[first[i] + j];
+            o.seg_rows = g[i].seg_rows; o.nseg = g[i].nseg; o.nstrip_wg = g[i].nstrip_wg; o.wg0 = g[i].wg0;
+        }
 }
 
 static inline void khg_fwd_args_common(KhgFwdArgs* a, const KhgWorkspace& ws, const uint8_t* r, const uint8_t* g,

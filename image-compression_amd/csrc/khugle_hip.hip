@@ -109,13 +109,13 @@ __global__ __launch_bounds__(256) void khg_dec_write_kernel(KhgDecArgs a)
     if (blk != ~0u) khg_dec_write_body(a, blk, sh);
 }
 
-// 32 KB of LDS allows 5 workgroups per CU = 5 waves per SIMD; the bound keeps the register count (<= 96) from
-// being what limits it instead (the kernel is latency-bound: 4 waves instead of 5 cost 30 %).
-template <int LEVEL, bool RGB>
-__global__ __launch_bounds__(256, 5) void khg_inv_kernel(KhgInvArgs a)
+// KIND: KHG_INV_PLANES2 (level 2 of the three components), KHG_INV_PLANES1 (level 1 into f64 planes),
+// KHG_INV_RGB (level 1 of the luma plane into the RGB image).
+template <int KIND>
+__global__ __launch_bounds__(256) void khg_inv_kernel(KhgInvArgs a)
 {
-    __shared__ KhgInvSmem sh;
-    khg_inv_strip_body<LEVEL, RGB>(a, (int)blockIdx.x, sh);
+    __shared__ KhgInvSmemAny sh;
+    khg_inv_launch_body<KIND>(a, (int)blockIdx.x, sh);
 }
 
 __global__ __launch_bounds__(256) void khg_ssim_kernel(KhgSsimArgs a)

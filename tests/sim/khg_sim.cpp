@@ -135,20 +135,20 @@ static int sim_decode(SimWs& S, const uint8_t* comp, size_t len, int rows, int c
     delete lsh2;
     delete wsh;
     delete ssh;
-    KhgInvSmem* ish = new KhgInvSmem;
-    KhgFwdGrid gr;
-    for (int p = 0; p < 3; ++p) {
-        KhgInvArgs a = khg_inv_args(S.ws, S.dws, rows, cols, p, 2, &gr, tile);
-        for (int bid = 0; bid < gr.nstrip * gr.nseg; ++bid) khg_inv_strip_body<2>(a, bid, *ish);
+    KhgInvSmemAny* ish = new KhgInvSmemAny;
+    {
+        const KhgInvArgs a = khg_inv_args(S.ws, S.dws, rows, cols, 0, 3, 2, tile);
+        for (int wg = 0; wg < a.nwg; ++wg) khg_inv_launch_body<KHG_INV_PLANES2>(a, wg, *ish);
     }
-    for (int p = 2; p >= 0; --p) {
-        KhgInvArgs a = khg_inv_args(S.ws, S.dws, rows, cols, p, 1, &gr, tile);
-        a.r = r; a.g = g; a.b = b;
-        if (ycbcr) a.dst = ycbcr[p];
-        for (int bid = 0; bid < gr.nstrip * gr.nseg; ++bid) {
-            if (p == 0 && !ycbcr) khg_inv_strip_body<1, true>(a, bid, *ish);
-            else khg_inv_strip_body<1, false>(a, bid, *ish);
-        }
+    if (ycbcr) {
+        const KhgInvArgs a = khg_inv_args(S.ws, S.dws, rows, cols, 0, 3, 1, tile, ycbcr);
+        for (int wg = 0; wg < a.nwg; ++wg) khg_inv_launch_body<KHG_INV_PLANES1>(a, wg, *ish);
+    } else {
+        const KhgInvArgs ac = khg_inv_args(S.ws, S.dws, rows, cols, 1, 2, 1, tile);
+        for (int wg = 0; wg < ac.nwg; ++wg) khg_inv_launch_body<KHG_INV_PLANES1>(ac, wg, *ish);
+        KhgInvArgs ay = khg_inv_args(S.ws, S.dws, rows, cols, 0, 1, 1, tile);
+        ay.r = r; ay.g = g; ay.b = b;
+        for (int wg = 0; wg < ay.nwg; ++wg) khg_inv_launch_body<KHG_INV_RGB>(ay, wg, *ish);
     }
     delete ish;
     size_t ny = (size_t)rows * cols;
