@@ -36,6 +36,11 @@ static inline KhgDecArgs khg_dec_args(const KhgWorkspace& ws, const KhgDecWorksp
     return d;
 }
 
+// Workgroups of the chip that an inverse launch is planned for.
+#ifndef KHG_INV_SLOTS
+#define KHG_INV_SLOTS 1024
+#endif
+
 // Plane of colour component comp at level 2 (into the LL buffer) or level 1 (into the component's f64 plane, or
 // dst when given) of an inverse launch, without its grid.
 // Tiles: every rank decodes the whole symbol planes, so a tile only restricts the rows it reconstructs: its band at
@@ -89,7 +94,7 @@ static inline KhgInvArgs khg_inv_args(const KhgWorkspace& ws, const KhgDecWorksp
         khg_inv_plane(&a.pl[i], ws, dws, rows, cols, comp0 + i, level, tile, dst ? dst[comp0 + i] : nullptr);
         g[i].pw = a.pl[i].pw; g[i].span = a.pl[i].row_end - a.pl[i].row_begin; g[i].weight = 1;
     }
-    a.nwg = khg_plan_groups(g, n, KHG_FWD_SLOTS);
+    a.nwg = khg_plan_groups(g, n, KHG_INV_SLOTS);
     for (int i = 0; i < n; ++i) {
         a.pl[i].seg_rows = g[i].seg_rows; a.pl[i].nseg = g[i].nseg; a.pl[i].nstrip_wg = g[i].nstrip_wg; a.pl[i].wg0 = g[i].wg0;
     }
