@@ -186,6 +186,21 @@ extern "C" int khg_decode_ycbcr(khg_ctx* c, const uint8_t* comp, size_t len, dou
 
 // ------------------------------------------------------------------ metrics
 
+// Per-block values into `blocks`, then their raster-order mean into d_mean[0] (both device memory).
+static int khg_ssim_enqueue(const uint8_t* d_a, const uint8_t* d_b, int width, int height, double* blocks, double* d_mean,
+                            hipStream_t st)
+{
+    const size_t nblk = (size_t)(width / 8) * (height / 8);
+    KhgSsimArgs a;
+    a.a = d_a; a.b = d_b; a.width = width; a.height = height; a.blocks = blocks;
+    hipLaunchKernelGGL(khg_ssim_kernel, dim3((unsigned)((nblk + 255) / 256)), dim3(256), 0, st, a);
+    KhgSsimMeanArgs m;
+    m.blocks = blocks; m.nblk = nblk; m.out = d_mean;
+    hipLaunchKernelGGL(khg_ssim_mean_kernel, dim3(1), dim3(256), 0, st, m);
+    KHG_HIP(hipGetLastError());
+    return KHG_OK;
+}
+
 extern "C" int khg_ssim_dev(khg_ctx* c, const uint8_t* d_a, const uint8_t* d_b, int width, int height, double* ssim,
                             void* stream)
 {
@@ -193,23 +208,36 @@ extern "C" int khg_ssim_dev(khg_ctx* c, const uint8_t* d_a, const uint8_t* d_b, 
     if (width < 8 || height < 8 || width > c->max_cols || height > c->max_rows) return KHG_ERR_DIMS;
     hipStream_t st = (hipStream_t)stream;
     KHG_HIP(hipSetDevice(c->device));
-    size_t nblk = (size_t)(width / 8) * (height / 8);
-    if (!c->h_ssim_blocks) {
-        size_t cap = ((size_t)c->max_rows / 8) * ((size_t)c->max_cols / 8);
-        KHG_HIP(hipHostMalloc((void**)&c->h_ssim_blocks, cap * sizeof(double)));
-    }
-    KhgSsimArgs a;
-    a.a = d_a; a.b = d_b; a.width = width; a.height = height; a.blocks = c->ssim_blocks;
-    hipLaunchKernelGGL(khg_ssim_kernel, dim3((unsigned)((nblk + 255) / 256)), dim3(256), 0, st, a);
-    KHG_HIP(hipGetLastError());
-    KHG_HIP(hipMemcpyAsync(c->h_ssim_blocks, c->ssim_blocks, nblk * sizeof(double), hipMemcpyDeviceToHost, st));
+    int rc = khg_ssim_enqueue(d_a, d_b, width, height, c->ssim_blocks, c->ssim_mean, st);
+    if (rc) return rc;
+    KHG_HIP(hipMemcpyAsync(ssim, c->ssim_mean, sizeof(double), hipMemcpyDeviceToHost, st));
     KHG_HIP(hipStreamSynchronize(st));
-    // SSIM.h:68-71: the mean is a sequential sum in raster order; done here so the result
-    // is bit-identical to the reference's (a parallel tree sum would differ in the last bits)
-    double sum = 0.0;
-    for (size_t i = 0; i < nblk; ++i) sum += c->h_ssim_blocks[i];
-    *ssim = sum / nblk;
     return KHG_OK;
+}
+
+// ---- the entry point that allocates nothing: per-block values go to a fixed array of the code object
+enum { KHG_SSIM_STATIC_BLOCKS = (7680 / 8) * (4320 / 8), KHG_MAX_DEVICES = 64 };
+static __device__ __align__(256) double khg_ssim_scratch[KHG_SSIM_STATIC_BLOCKS];
+static double* g_ssim_scratch_ptr[KHG_MAX_DEVICES];  // device address of the array on each device, once looked up
+
+extern "C" int khg_ssim_static_dev(const uint8_t* d_a, const uint8_t* d_b, int width, int height, double* d_ssim,
+                                   void* stream)
+{
+    if (!d_a || !d_b || !d_ssim) return KHG_ERR_ARG;
+    if (width < 8 || height < 8) return KHG_ERR_DIMS;
+    if ((size_t)(width / 8) * (size_t)(height / 8) > (size_t)KHG_SSIM_STATIC_BLOCKS) return KHG_ERR_DIMS;  // beyond the fixed array
+    int dev = -1;
+    KHG_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= KHG_MAX_DEVICES) return KHG_ERR_HIP;
+    double* scratch = __atomic_load_n(&g_ssim_scratch_ptr[dev], __ATOMIC_ACQUIRE);
+    if (!scratch) {  // first call on this device: each device holds its own copy of the array at its own address
+        void* p = nullptr;
+        KHG_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(khg_ssim_scratch)));
+        if (!p) return KHG_ERR_HIP;
+        scratch = (double*)p;
+        __atomic_store_n(&g_ssim_scratch_ptr[dev], scratch, __ATOMIC_RELEASE);
+    }
+    return khg_ssim_enqueue(d_a, d_b, width, height, scratch, d_ssim, (hipStream_t)stream);
 }
 
 extern "C" int khg_psnr_dev(khg_ctx* c, const uint8_t* d_ir, const uint8_t* d_ig, const uint8_t* d_ib,

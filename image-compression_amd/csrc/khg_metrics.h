@@ -46,6 +46,42 @@ KHG_DEV void khg_ssim_body(const KhgSsimArgs& a, uint32_t bid)
     }
 }
 
+// Mean of the per-block values (SSIM.h:66-71): the reference adds them one after another in raster order, and a
+// double sum depends on its order, so one lane does exactly that; the other threads only bring the values into
+// LDS, a coalesced chunk at a time.  One workgroup of 256 threads.
+enum { KHG_SSIM_CHUNK = 2048 };
+struct KhgSsimMeanSmem {
+    double v[KHG_SSIM_CHUNK];
+    double sum;
+};
+struct KhgSsimMeanArgs {
+    const double* blocks;
+    size_t nblk;
+    double* out;  // [1]
+};
+KHG_DEV void khg_ssim_mean_body(const KhgSsimMeanArgs& a, KhgSsimMeanSmem& sh)
+{
+    KHG_FOR_THREADS(256) { if (tid == 0) sh.sum = 0.0; }
+    for (size_t c0 = 0; c0 < a.nblk; c0 += KHG_SSIM_CHUNK) {
+        const int n = (int)(a.nblk - c0 < (size_t)KHG_SSIM_CHUNK ? a.nblk - c0 : (size_t)KHG_SSIM_CHUNK);
+        KHG_FOR_THREADS(256)
+        {
+            for (int i = tid; i < n; i += 256) sh.v[i] = a.blocks[c0 + i];
+        }
+        KHG_BARRIER();
+        KHG_FOR_THREADS(256)
+        {
+            if (tid == 0) {
+                double s = sh.sum;
+                for (int i = 0; i < n; ++i) s += sh.v[i];
+                sh.sum = s;
+            }
+        }
+        KHG_BARRIER();
+    }
+    KHG_FOR_THREADS(256) { if (tid == 0) a.out[0] = sh.sum / (double)a.nblk; }
+}
+
 struct KhgSseArgs {
     const uint8_t* in[3];
     const uint8_t* out[3];

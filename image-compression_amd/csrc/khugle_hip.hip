@@ -123,6 +123,12 @@ __global__ __launch_bounds__(256) void khg_ssim_kernel(KhgSsimArgs a)
     khg_ssim_body(a, blockIdx.x);
 }
 
+__global__ __launch_bounds__(256) void khg_ssim_mean_kernel(KhgSsimMeanArgs a)
+{
+    __shared__ KhgSsimMeanSmem sh;
+    khg_ssim_mean_body(a, sh);
+}
+
 __global__ __launch_bounds__(256) void khg_sse_kernel(KhgSseArgs a)
 {
     __shared__ KhgSseSmem sh;
@@ -159,7 +165,7 @@ struct khg_ctx {
     size_t stage_comp_bytes;
     double* stage_f64;   // 2 x (Y + Cb + Cr) f64 planes for the host YCbCr entry points
     double* ssim_blocks; // per-block SSIM values
-    double* h_ssim_blocks;
+    double* ssim_mean;   // [1] their mean
     unsigned long long* sse; // [3] sums of squared errors
     // optional timing of the luma forward launch inside khg_encode_dev (khg_profile_luma_forward)
     int prof_on, prof_pending, prof_launches;
@@ -224,7 +230,7 @@ extern "C" int khg_ctx_create(int device, int max_rows, int max_cols, khg_ctx** 
     size_t o_plane[3];
     for (int p = 0; p < 3; ++p) o_plane[p] = take(ds.plane[p]);
     size_t o_lut = take(ds.lut), o_lut2 = take(ds.lut2), o_blk = take(ds.blk), o_walk = take(ds.walk), o_hdr = take(sizeof(KhgDecHeader));
-    size_t o_ssim = take(nblk * sizeof(double)), o_sse = take(64);
+    size_t o_ssim = take(nblk * sizeof(double)), o_sse = take(64), o_mean = take(64);
     c->slab_bytes = total;
     if (hipMalloc(&c->slab, total) != hipSuccess) { delete c; return KHG_ERR_NOMEM; }
     char* base = (char*)c->slab;
@@ -243,6 +249,7 @@ extern "C" int khg_ctx_create(int device, int max_rows, int max_cols, khg_ctx** 
     c->dws.hdr = (KhgDecHeader*)(base + o_hdr);
     c->ssim_blocks = (double*)(base + o_ssim);
     c->sse = (unsigned long long*)(base + o_sse);
+    c->ssim_mean = (double*)(base + o_mean);
     // hipMemset of device memory may return before the fill has run, and the fill is on the null stream, which
     // non-blocking streams do not wait for: drain it here, so that no work of the caller can overtake it.
     if (hipMemset(c->slab, 0, total) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess ||
@@ -264,7 +271,6 @@ extern "C" void khg_ctx_destroy(khg_ctx* c)
     if (c->stage_rgb) (void)hipFree(c->stage_rgb);
     if (c->stage_comp) (void)hipFree(c->stage_comp);
     if (c->h_res) (void)hipHostFree(c->h_res);
-    if (c->h_ssim_blocks) (void)hipHostFree(c->h_ssim_blocks);
     if (c->stage_f64) (void)hipFree(c->stage_f64);
     if (c->done) (void)hipEventDestroy(c->done);
     if (c->prof_e0) (void)hipEventDestroy(c->prof_e0);

@@ -104,12 +104,24 @@ int khg_decode_ycbcr_dev(khg_ctx *ctx, const uint8_t *d_comp, size_t len, int ro
 
 /* ---- quality metrics: ComputeSSIM (SSIM.h:57-72; the application passes the R channel only,
  * Main.cpp:250-253) and GetPsnr (KhuGleBase.cpp:613-627).  Device planes, synchronous result.
- * Per-block SSIM values are bit-exact; *ssim is their sum in raster order divided by the count. */
+ * Per-block SSIM values are bit-exact; *ssim is their sum in raster order divided by the count, added up on the
+ * device by one lane in the reference's order (SSIM.h:66-71), so it is bit-identical too. */
 int khg_ssim_dev(khg_ctx *ctx, const uint8_t *d_a, const uint8_t *d_b, int width, int height, double *ssim,
                  void *stream);
 int khg_psnr_dev(khg_ctx *ctx, const uint8_t *d_ir, const uint8_t *d_ig, const uint8_t *d_ib,
                  const uint8_t *d_or, const uint8_t *d_og, const uint8_t *d_ob, int width, int height, double *psnr,
                  void *stream);
+
+/* ---- an entry point that allocates nothing.  It has no counterpart in the reference: it exists for callers that
+ * cannot allocate device or pinned memory -- code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc -- and therefore cannot hold a khg_ctx either.  It is khg_ssim_dev with its scratch (the per-block
+ * values) in a fixed array that is part of the library's code object on every GPU: at most 7680 x 4320 pixels
+ * (518400 blocks, 4 MB per GPU until the process ends); larger images are refused with KHG_ERR_DIMS.  It works on
+ * the calling thread's current device, enqueues on `stream` and does not synchronise: the result is written to
+ * DEVICE memory at d_ssim[0] (bit-identical to khg_ssim_dev's) and is valid once the stream has run.  No hipMalloc,
+ * hipFree or other allocating call is made.  All calls on one GPU share the one array: calls that overlap in time
+ * on a GPU (different streams) race; nothing in it needs to start at zero. */
+int khg_ssim_static_dev(const uint8_t *d_a, const uint8_t *d_b, int width, int height, double *d_ssim, void *stream);
 
 /* ---- parity taps (device pointers, synchronous).  Any output pointer may be NULL.
  * khg_forward_planes_dev: Y/Cb/Cr after the two FWT2D levels (Compress.h:108-114), f64, row-major.

@@ -317,10 +317,14 @@ double khgsim_ssim(const uint8_t* a, const uint8_t* b, int width, int height, do
     KhgSsimArgs s;
     s.a = a; s.b = b; s.width = width; s.height = height; s.blocks = blocks.data();
     for (uint32_t bid = 0; bid < (nblk + 255) / 256; ++bid) khg_ssim_body(s, bid);
-    double sum = 0.0;
-    for (size_t i = 0; i < nblk; ++i) sum += blocks[i];
     if (blocks_out) memcpy(blocks_out, blocks.data(), nblk * sizeof(double));
-    return sum / nblk;
+    double mean = 0.0;
+    KhgSsimMeanArgs m;
+    m.blocks = blocks.data(); m.nblk = nblk; m.out = &mean;
+    KhgSsimMeanSmem* msh = new KhgSsimMeanSmem;
+    khg_ssim_mean_body(m, *msh);
+    delete msh;
+    return mean;
 }
 
 void khgsim_sse(const uint8_t* const in[3], const uint8_t* const out[3], size_t n, unsigned long long sse[3]) {
