@@ -26,11 +26,23 @@ def test_decode_reference_comp_files(codec, ref):
 @pytest.mark.parametrize("name", IMAGES)
 @pytest.mark.parametrize("lvl", [0, 1, 2])
 def test_roundtrip_run_images(codec, run_images, name, lvl):
+    import hashlib
     import oracle_py as O
     rgb = run_images[name]
     comp = codec.encode(rgb, lvl)
     got = codec.decode(comp)
     assert np.array_equal(got, O.decode(comp))
+    # the picture the reference's own decoder produced for this file (tests/golden/make_decode_sha256.py)
+    golden = json.load(open(os.path.join(GOLDEN, "decode_sha256.json")))
+    assert hashlib.sha256(got.tobytes()).hexdigest() == golden["%s_%d" % (name, lvl)]
+
+
+@pytest.mark.parametrize("ref", ["cat_high", "couple_normal", "library_extreme"])
+def test_decode_reference_comp_files_golden_pixels(codec, ref):
+    import hashlib
+    golden = json.load(open(os.path.join(GOLDEN, "decode_sha256.json")))
+    comp = open(os.path.join(RUN, ref + ".comp"), "rb").read()
+    assert hashlib.sha256(codec.decode(comp).tobytes()).hexdigest() == golden[ref + ".comp"]
 
 
 def test_published_quality_figures(codec, run_images):

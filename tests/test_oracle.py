@@ -137,3 +137,34 @@ def test_ref_hybrid_files_match_oracle(tmp_path, run_images):
         assert R.kref_decode_file(path, out[0], out[1], out[2], C.byref(nn)) == 0
         assert nn.value == n and np.array_equal(out, O.decode(got))
         assert R.kref_ssim(rgb[0], out[0], n, n) == O.ssim(rgb[0], out[0])
+
+
+def test_decoded_pictures_match_the_reference_decoder(run_images):
+    """Decode side: the oracle's pictures for all 27 files and the three shipped .comp files hash to what the
+    reference's own reader / Huffman decoder / inverse DWT produced (tests/golden/make_decode_sha256.py)."""
+    import hashlib
+    import json
+    import os
+    from conftest import GOLDEN, IMAGES, RUN
+    golden = json.load(open(os.path.join(GOLDEN, "decode_sha256.json")))
+    for name in IMAGES:
+        for lvl in (0, 1, 2):
+            pic = O.decode(O.encode(run_images[name], lvl))
+            assert hashlib.sha256(pic.tobytes()).hexdigest() == golden["%s_%d" % (name, lvl)], (name, lvl)
+    for f in ("cat_high", "couple_normal", "library_extreme"):
+        pic = O.decode(open(os.path.join(RUN, f + ".comp"), "rb").read())
+        assert hashlib.sha256(pic.tobytes()).hexdigest() == golden[f + ".comp"]
+
+
+def test_simulated_decoder_matches_the_reference_decoder():
+    import hashlib
+    import json
+    import os
+    import simlib as S
+    from conftest import GOLDEN, RUN
+    golden = json.load(open(os.path.join(GOLDEN, "decode_sha256.json")))
+    for f in ("cat_high", "couple_normal", "library_extreme"):
+        comp = open(os.path.join(RUN, f + ".comp"), "rb").read()
+        hd = O.peek(comp)
+        rc, pic, _, _ = S.decode(comp, hd.h, hd.w)
+        assert rc == 0 and hashlib.sha256(pic.tobytes()).hexdigest() == golden[f + ".comp"]
