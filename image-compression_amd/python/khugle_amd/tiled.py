@@ -101,7 +101,9 @@ class HipTileBackend:
     def pack(self, cap):
         share = torch.empty(cap, dtype=torch.uint8, device=self.dev)
         _check(self.L.khg_tile_pack_dev(self.c._ctx, _ptr(share), cap, _stream()), "tile_pack")
-        return share, self.c.encode_result()
+        n = C.c_size_t(0)
+        status = self.L.khg_encode_result(self.c._ctx, C.byref(n))  # device-side status of this rank's tile: not raised here
+        return share, n.value, status
 
     def decode(self, comp, length, rows, cols, rank, world):
         r0, r1 = tile_rows(rows, rank, world)
@@ -151,7 +153,15 @@ def encode_tiled(backend, strip, rows, cols, lvl, rank, world, coll=None, dst=0)
     bits = backend.bits_get()
     coll.all_reduce_sum(bits)
     backend.bits_set(bits)
-    share, total = backend.pack(backend.comp_bound(rows, cols))
+    share, total, status = backend.pack(backend.comp_bound(rows, cols))
+    # A failure (a symbol out of range, a stream of 2^31 bits) may show on one rank only.  The ranks agree on the
+    # status before the byte reduce, so that all of them raise together instead of one raising and the others
+    # waiting in the reduce for ever.
+    st = torch.tensor([status], dtype=torch.int32, device=share.device)
+    coll.all_reduce_min(st)
+    worst = int(st.item())
+    if worst != 0:
+        raise _lib.KhgError(worst, "encode_tiled (rank %d saw status %d)" % (rank, status))
     words = share[: (total + 3) & ~3].view(torch.int32)
     coll.reduce_sum(words, dst)  # the shares have no set bit in common: their sum is their OR
     if rank != dst:

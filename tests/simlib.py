@@ -221,8 +221,7 @@ class SimTileBackend:
         share = self.torch.empty(cap, dtype=self.torch.uint8)
         total = C.c_size_t(0)
         rc = lib().khgsim_tile_pack(self.h, share.data_ptr(), cap, C.byref(total))
-        assert rc == 0, rc
-        return share, total.value
+        return share, total.value, rc
 
     def decode(self, comp, length, rows, cols, rank, world):
         out = self.torch.empty((3, rows // world, cols), dtype=self.torch.uint8)

@@ -91,6 +91,46 @@ def test_two_gloo_ranks_exchange_halos_and_histograms(tmp_path):
     assert open(out, "rb").read() == O.encode(synth_frame(rows, cols, 11, 0), lvl)
 
 
+def _gloo_rank_failing(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from khugle_amd import tiled
+    from khugle_amd.lib import KhgError
+    from khugle_amd.synth import synth_frame
+    import simlib as S
+    rows, cols = 128, 96
+
+    class Failing(S.SimTileBackend):  # rank 1's tile reports "value out of range", rank 0's is fine
+        def pack(self, cap):
+            share, total, rc = super().pack(cap)
+            return share, total, (-4 if rank == 1 else rc)
+
+    rgb = synth_frame(rows, cols, 11, 0)
+    i0, i1 = tiled.input_rows(rows, rank, world)
+    strip = torch.from_numpy(np.ascontiguousarray(rgb[:, i0:i1]))
+    try:
+        tiled.encode_tiled(Failing(rows, cols), strip, rows, cols, 1, rank, world)
+        outcome = "returned"
+    except KhgError as e:
+        outcome = "raised %d" % e.code
+    with open(os.path.join(out_dir, "rank%d.txt" % rank), "w") as f:
+        f.write(outcome)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_a_failing_tile_fails_every_rank_instead_of_hanging(tmp_path):
+    world = 2
+    ctx = mp.spawn(_gloo_rank_failing, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=False)
+    import time
+    deadline = time.time() + 120
+    while not ctx.join(timeout=5):  # join() returns after each process that ends
+        assert time.time() < deadline, "ranks hung"
+    for r in range(world):
+        assert open(os.path.join(str(tmp_path), "rank%d.txt" % r)).read() == "raised -4"
+
+
 def test_tile_geometry():
     from khugle_amd import tiled
     assert tiled.tile_rows(256, 1, 4) == (64, 128)
