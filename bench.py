@@ -8,10 +8,11 @@ back to RGB (device to device).  Frames are independent, so ranks exchange nothi
 path (weak scaling); torch.distributed (RCCL) only provides the barrier and the max-over-ranks.
 
 Prints ONE JSON line on rank 0.  `value` = megapixels that went through encode AND decode per
-second, whole job.  `roofline` prices the longest kernel (level-1 luma forward transform) against
-the 8 TB/s HBM peak with HIP-event timing taken live; `cpu_baseline` times the reference's own
-DWT / Huffman / file code (oracle/_ref, built from the reference's headers) on the host cores
-on a bounded sample.
+second, whole job.  `roofline` prices the longest data-parallel kernel (the level-1 forward launch:
+colour conversion, DWT level 1, quantiser and histogram of Y, Cb and Cr) against the 8 TB/s HBM
+peak with timing taken live; `cpu_baseline` times the reference's own DWT / Huffman / file code
+(oracle/_ref, built from the reference's headers) on the host cores on a bounded sample: one
+5760x5760 frame (the square 8K-class shape the reference can round-trip) per core.
 """
 import argparse
 import json
@@ -26,14 +27,15 @@ for _p in (os.path.join(ROOT, "image-compression_amd", "python"), os.path.join(R
 
 ROWS, COLS, LVL, SEED = 4320, 7680, 1, 2025
 HBM_PEAK_GBS = 8000.0
-# level-1 luma forward kernel, algorithmic bytes per luma pixel: 3 (u8 R,G,B read)
-# + 2 (LL quadrant written as f64: 8 B on a quarter of the samples)
-# + 1.5 (int16 symbols of the three detail sub-bands: 2 B on three quarters)
-LUMA_FWD_BYTES_PER_PX = 6.5
-# the same launch priced by the pass-structured model (one kernel per stage, f64 planes between the stages): the luma
-# share of colour conversion (3 read + 8 written), DWT level 1 (8 + 8) and quantisation of the three detail
-# bands (three quarters of 8 read + 2 written)
-LUMA_FWD_STAGED_BYTES_PER_PX = 11 + 16 + 7.5
+# Level-1 forward launch (colour + DWT level 1 + quantiser + histogram of Y, Cb and Cr in one kernel, the longest
+# data-parallel kernel of the path), algorithmic bytes per luma pixel:
+#   3     u8 R, G, B read once
+# + 3     LL quadrants written as f64 for level 2 (8 B on a quarter of the 1.5 samples per pixel)
+# + 2.25  int16 symbols of the three detail sub-bands (2 B on three quarters of the 1.5 samples)
+L1_FWD_BYTES_PER_PX = 8.25
+# the same launch priced by the pass-structured model (one kernel per stage, f64 planes between the stages): colour
+# conversion (3 read + 12 written), DWT level 1 (12 + 12) and quantisation of the detail bands (9 read + 2.25 written)
+L1_FWD_STAGED_BYTES_PER_PX = 15 + 24 + 11.25
 
 
 def _cpu_worker(args):
@@ -72,7 +74,7 @@ def _cpu_worker(args):
     return time.perf_counter() - t0, te, td
 
 
-def cpu_baseline(side=2048, frames_per_core=3):
+def cpu_baseline(side=5760, frames_per_core=1):
     import multiprocessing as mp
     import oracle_py as O
     cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
@@ -91,6 +93,7 @@ def cpu_baseline(side=2048, frames_per_core=3):
     what = ("reference DWT.h/Huffman.h/Writer.h/Reader.h compiled as they are + restated colour/quantiser"
             if kind == "reference" else "CPU restatement with the reference's O(N*K) table search")
     return {"value": round(mp_total / busy, 3), "unit": "MP/s encode+decode", "cores": cores, "kind": kind,
+            "frames_timed": cores * frames_per_core,
             "sample": "%d frames of %dx%d (same generator, seed %d, High preset; the reference cannot "
                       "round-trip non-square frames), one process per core, %s; per core: encode %.2f MP/s, "
                       "decode %.2f MP/s; pool wall %.1f s" % (cores * frames_per_core, side, side, SEED, what,
@@ -207,7 +210,6 @@ def main():
     k_launches = sum(n for _, _, n in prof)
     k_event_ms = sum(ms for ms, _, _ in prof) / max(1, k_launches)
     k_ms = sum(dv for _, dv, _ in prof) / max(1, k_launches)
-    achieved = LUMA_FWD_BYTES_PER_PX * px / (k_ms * 1e-3) / 1e9
     k_alone_ms = None
     if not args.no_isolated_kernel:
         with torch.cuda.stream(streams[0]):
@@ -308,13 +310,49 @@ def main():
             parity = bool(comp == want) and bool(np.array_equal(dec, O.decode(want)))
         except Exception as e:  # the oracle is test infrastructure: never let it break the measurement
             parity = "unavailable: %s" % e
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "luma_forward_traffic.json")
+        # HBM bytes per launch from the counters and the per-kernel table: collected by tools/gpu_roofline.sh
+        # (rocprofv3 --kernel-trace --stats and one --pmc pass each for FETCH_SIZE and WRITE_SIZE), committed
+        traffic = per_kernel = None
+        tpath = os.path.join(ROOT, "profiles", "r02_kernels.json")
         if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            prof_table = json.load(open(tpath))
+            traffic = prof_table["kernels"].get("khg_fwd_kernel<0>", {}).get("traffic_bytes")
+            per_kernel = {k: {f: v[f] for f in ("avg_us", "algorithmic_bytes", "traffic_bytes", "frac") if f in v}
+                          for k, v in prof_table["kernels"].items()}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline()
+        l1_bytes = L1_FWD_BYTES_PER_PX * px
+
+        def priced(ms):
+            gbs = l1_bytes / (ms * 1e-3) / 1e9
+            return {"avg_launch_ms": round(ms, 4), "achieved": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)}
+
+        # `achieved` / `frac`: the kernel's own duration, i.e. launches on an otherwise idle GPU timed with HIP events
+        # on the stream they run on (what rocprofv3 reports for the one-stream profile committed under profiles/).
+        # `in_timed_region`: the same kernel's launches inside the timed region, where 24 streams share the GPU and a
+        # launch's span (first workgroup start to last workgroup end, device clock) also covers the time its
+        # workgroups wait for CUs held by other frames' kernels -- a lower bound on the kernel's rate, not its cost.
+        main = priced(k_alone_ms) if k_alone_ms is not None else priced(k_ms)
+        roofline = {"bound": "hbm",
+                    "kernel": "khg_fwd_kernel<0> (colour + DWT level 1 + quantiser + histogram of Y, Cb, Cr)",
+                    "achieved": main["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": main["frac"],
+                    "traffic": traffic, "bytes_per_launch": l1_bytes, "avg_launch_ms": main["avg_launch_ms"],
+                    "timing": ("20 launches on an idle GPU after the timed region, HIP events on the launch stream"
+                               if k_alone_ms is not None else "launches inside the timed region (device clock span)"),
+                    "in_timed_region": dict(priced(k_ms), launches_timed=k_launches,
+                                            event_avg_launch_ms=round(k_event_ms, 4),
+                                            note="span of the launches that ran inside the timed region next to the "
+                                                 "other streams' kernels; event_avg_launch_ms also counts the wait "
+                                                 "for the GPU"),
+                    "staged_model": {"bytes_per_px": L1_FWD_STAGED_BYTES_PER_PX,
+                                     "note": "what the stages fused into this launch would move as separate passes "
+                                             "with f64 planes between them; the launch is priced at its compulsory "
+                                             "8.25 B/px"},
+                    "per_kernel_profile": per_kernel,
+                    "per_kernel_profile_note": "one-stream 8K frame under rocprofv3 (profiles/r02_kernels.json, made by "
+                                               "tools/gpu_roofline.sh): avg_us, algorithmic and counter bytes per "
+                                               "launch, fraction of the 8 TB/s HBM peak"}
         total_mp = world * F * args.steps * px / 1e6
         bpp = 8.0 * sum(lens) / (F * px)
         line = {
@@ -337,27 +375,7 @@ def main():
             "encode_mp_s": round(total_mp / t_enc, 1),
             "decode_mp_s": round(total_mp / t_dec, 1),
             "parity_spot_check": parity,
-            "roofline": {"bound": "hbm", "kernel": "khg_fwd_kernel<0,1> (colour + DWT level 1 + quantiser + histogram, luma)",
-                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "bytes_per_launch": LUMA_FWD_BYTES_PER_PX * px, "avg_launch_ms": round(k_ms, 4),
-                         "launches_timed": k_launches,
-                         "staged_model": {
-                             "bytes_per_px": LUMA_FWD_STAGED_BYTES_PER_PX,
-                             "achieved": round(LUMA_FWD_STAGED_BYTES_PER_PX * px / (k_ms * 1e-3) / 1e9, 1),
-                             "frac": round(LUMA_FWD_STAGED_BYTES_PER_PX * px / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                             "note": "what the stages fused into this launch would move as separate passes; the "
-                                     "launch itself is priced above at its compulsory 6.5 B/px"},
-                         "event_avg_launch_ms": round(k_event_ms, 4),
-                         "note": "avg_launch_ms: execution span (first workgroup start to last workgroup end, device "
-                                 "clock) of the launches inside the timed region, where the kernel shares the GPU "
-                                 "with the other streams' kernels -- the duration a profiler reports; "
-                                 "event_avg_launch_ms: HIP events around the same launches, which also count the "
-                                 "wait for the GPU; `alone`: the same kernel on an idle GPU (HIP events)",
-                         "alone": None if k_alone_ms is None else {
-                             "avg_launch_ms": round(k_alone_ms, 4),
-                             "achieved": round(LUMA_FWD_BYTES_PER_PX * px / (k_alone_ms * 1e-3) / 1e9, 1),
-                             "frac": round(LUMA_FWD_BYTES_PER_PX * px / (k_alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}},
+            "roofline": roofline,
             "cpu_baseline": cpu,
             # the pass-structured traffic model of the path (63 + c bytes per pixel each way, c = .comp bytes
             # per pixel): what a stage-per-kernel pipeline would move; fusion keeps the real traffic below it

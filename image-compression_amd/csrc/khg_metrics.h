@@ -73,7 +73,15 @@ KHG_DEV void khg_ssim_mean_body(const KhgSsimMeanArgs& a, KhgSsimMeanSmem& sh)
         {
             if (tid == 0) {
                 double s = sh.sum;
-                for (int i = 0; i < n; ++i) s += sh.v[i];
+                int i = 0;
+                for (; i + 8 <= n; i += 8) {  // eight values fetched ahead of the chain of additions
+                    double t[8];
+                    KHG_UNROLL
+                    for (int u = 0; u < 8; ++u) t[u] = sh.v[i + u];
+                    KHG_UNROLL
+                    for (int u = 0; u < 8; ++u) s += t[u];
+                }
+                for (; i < n; ++i) s += sh.v[i];
                 sh.sum = s;
             }
         }
