@@ -123,6 +123,15 @@ KHG_DEV bool khg_round_quot_fast(double c, double rdiv, double* n_out)
 // Whole-sample symmetric extension of index i onto [0, n), any i (n even, >= 2).
 // The reference's boundary lines x[n-1] += 2*a*x[n-2] and x[0] += 2*a*x[1] (DWT.h:18,26,34,42)
 // equal the interior formula on this extension bit for bit: 2*a*x == a*(x + x) exactly.
+// Rows [*r0, *r1) of segment `seg` of `nseg` over the even row range [begin, end): the row pairs are dealt out evenly,
+// segments differ by at most one pair.
+KHG_DEV void khg_segment_rows(int begin, int end, int nseg, int seg, int* r0, int* r1)
+{
+    const long long hp = (end - begin) / 2;
+    *r0 = begin + 2 * (int)(hp * seg / nseg);
+    *r1 = begin + 2 * (int)(hp * (seg + 1) / nseg);
+}
+
 KHG_DEV int khg_reflect(int i, int n)
 {
     if ((unsigned)i < (unsigned)n) return i;

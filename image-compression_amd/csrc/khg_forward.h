@@ -6,10 +6,12 @@
 //            s1[p+1], d2[p-1]); those come from the neighbouring LANE by a DPP wave shift, so a row is transformed
 //            where it was loaded, with no window recomputed per thread, no staging tile and no barrier.  The two
 //            pairs at each end of a strip are halo (their results are wrong and not used): 60 of 64 pairs are output.
-//            A lane at the end of a wave receives its own value back, which is exactly the whole-sample mirror the
-//            reference applies at the plane's edge (DWT.h:18,26,34,42), so the first strip starts at pair 0 on
-//            lane 0 and the last one ends on lane 63 and the plane's edges need no special code (planes narrower
-//            than a wave patch the one lane that holds their last pair).
+//            Halo pairs that fall outside the plane are LOADED mirrored (whole-sample symmetric extension about the
+//            first and the last sample: x[-i] = x[i], x[n-1+i] = x[n-1-i]).  Lifting preserves that symmetry and
+//            a + b == b + a bit for bit, so the interior formula then yields exactly what the reference's edge
+//            lines compute (DWT.h:18,26,34,42: x[n-1] += 2*a*x[n-2], x[0] += 2*a*x[1], and 2*a*x == a*(x+x)), and
+//            the row pass has no edge case at all.  A mirrored pair is the memory pair (x[i], x[i+1]) read backwards,
+//            so a lane carries its load column and which of the two samples is its even one.
 //   columns: the lane's two packed output columns (low half p, high half w/2 + p) each run the streaming lifting
 //            pipeline of khg_fwd_step over the rows as they arrive, state in registers.  Finished coefficients are
 //            scaled and emitted at once: level-1 LL to an f64 buffer (input of level 2), everything else quantised
@@ -48,7 +50,7 @@ struct KhgFwdPlane {
     int row_begin, row_end;    // plane rows this launch transforms (even; the whole plane, or one tile's band)
     int emit_k0, emit_k1;      // row pairs whose detail symbols are stored and counted (a tile recomputes its
                                // neighbours' edge rows for the LL quadrant only)
-    int seg_rows;              // rows per workgroup segment (even)
+    int seg_rows;              // rows of the tallest workgroup segment (even; see khg_segment_rows)
     int nseg;                  // segments
     int nstrip_wg;             // workgroups side by side (KHG_WG_STRIPS strips each)
     int wg0;                   // first workgroup of this plane in the launch
@@ -125,8 +127,7 @@ KHG_DEV double khg_fwd_scale_even(double x)
 KHG_DEV double khg_fwd_scale_odd(double x) { const double a = 1 / 1.149604398; return x * a; }
 
 // ---- neighbour lanes.  khg_lane_next(v): the value lane l+1 holds, khg_lane_prev(v): lane l-1's.  What the lane
-// at the end of a wave receives is unspecified (whatever its destination register held): inside the plane that
-// lane is halo, and at the plane's edge the caller substitutes the lane's own value (the whole-sample mirror).
+// at the end of a wave receives is unspecified (whatever its destination register held): that lane is halo.
 #ifndef KHG_SIM
 __device__ __forceinline__ double khg_lane_next(double v)
 {
@@ -185,8 +186,55 @@ KHG_DEV uint32_t khg_fwd_row_offset(const KhgFwdArgs& a, const KhgFwdPlane& pl, 
     return (uint32_t)khg_band_row(a, SRC == KHG_SRC_Y ? y : 2 * y) * (uint32_t)a.img_w;
 }
 
-// Two rows of the plane at row offsets oa, ob (khg_fwd_row_offset); col = the lane's column offset in elements
-// (2 p for Y and planes, 4 p for chroma).  Offsets are 32-bit: a plane has fewer than 2^31 samples.
+// Offsets of the two source rows of row pair j (plane rows 2j and 2j+1, reflected into the plane).  Nearly every
+// trip's rows are plain rows of the plane and of the r/g/b band: that case is a few scalar instructions.
+template <int SRC>
+KHG_DEV void khg_fwd_row_offsets(const KhgFwdArgs& a, const KhgFwdPlane& pl, int j, uint32_t& oa, uint32_t& ob)
+{
+    const int ya = 2 * j, ph = KHG_UNIFORM(pl.ph);
+    if (ya >= 0 && ya + 1 < ph) {
+        if (SRC == KHG_SRC_PLANE) {
+            oa = (uint32_t)ya * (uint32_t)KHG_UNIFORM(pl.src_pitch);
+            ob = oa + (uint32_t)KHG_UNIFORM(pl.src_pitch);
+            return;
+        }
+        const int f = SRC == KHG_SRC_Y ? 1 : 2;
+        const int ra = f * ya - KHG_UNIFORM(a.in_row0), rb = ra + f;
+        if (ra >= 0 && rb < KHG_UNIFORM(a.in_rows)) {
+            oa = (uint32_t)ra * (uint32_t)KHG_UNIFORM(a.img_w);
+            ob = (uint32_t)rb * (uint32_t)KHG_UNIFORM(a.img_w);
+            return;
+        }
+    }
+    oa = KHG_UNIFORM(khg_fwd_row_offset<SRC>(a, pl, khg_reflect(ya, ph)));
+    ob = KHG_UNIFORM(khg_fwd_row_offset<SRC>(a, pl, khg_reflect(ya + 1, ph)));
+}
+
+// Where a lane's pair (x[2p], x[2p+1]) is read from: both samples reflected into the row (p may lie up to two pairs
+// outside the plane, and anywhere for lanes beyond the last strip, whose loads are not used).  The two reflected
+// columns are always neighbours; `col` is the lower one and `swap` says that it holds the odd sample.
+struct KhgLaneSrc {
+    uint32_t col;  // column offset of the load in elements of the source (pixels for RGB)
+    uint32_t she;  // RGB: bit position of the even sample's byte in the loaded word; planes: nonzero = swapped
+    uint32_t sho;  // RGB: bit position of the odd sample's byte
+};
+
+template <int SRC>
+KHG_DEV KhgLaneSrc khg_fwd_lane_src(int p, int pw)
+{
+    const int ec = khg_reflect(2 * p, pw), oc = khg_reflect(2 * p + 1, pw);
+    const bool swap = ec > oc;
+    const uint32_t lo = (uint32_t)(swap ? oc : ec);
+    const uint32_t sh = SRC == KHG_SRC_Y ? 8u : 16u;  // distance of the pair's samples in the word: chroma sites are
+    KhgLaneSrc l;                                     // every second pixel (Colorspace.h:16-21)
+    l.col = SRC == KHG_SRC_C ? 2u * lo : lo;
+    l.she = swap ? sh : 0u;
+    l.sho = swap ? 0u : sh;
+    return l;
+}
+
+// Two rows of the plane at row offsets oa, ob (khg_fwd_row_offsets), at the lane's column.  Offsets are 32-bit: a
+// plane has fewer than 2^31 samples.  Loads of 2 / 4 / 16 bytes at any 1 / 2 / 8-byte boundary.
 template <int SRC>
 KHG_DEV void khg_fwd_fetch(const KhgFwdArgs& a, const KhgFwdPlane& pl, KhgFwdRaw<SRC>& raw, uint32_t oa, uint32_t ob,
                            uint32_t col)
@@ -208,16 +256,20 @@ KHG_DEV void khg_fwd_fetch(const KhgFwdArgs& a, const KhgFwdPlane& pl, KhgFwdRaw
 // Samples (even, odd) of row rr (0: a, 1: b) of channel n (Y / plane: 0; chroma: 0 = Cb, 1 = Cr) as the f64 values
 // the transform runs on.  Main.cpp:200-202 widens u8 to double; Colorspace.h:11,19,20: products and sums left to right.
 template <int SRC>
-KHG_DEV void khg_fwd_samples(const KhgFwdRaw<SRC>& raw, int rr, int n, double& e, double& o)
+KHG_DEV void khg_fwd_samples(const KhgFwdRaw<SRC>& raw, const KhgLaneSrc& ls, int rr, int n, double& e, double& o)
 {
     if constexpr (SRC == KHG_SRC_PLANE) {
-        __builtin_memcpy(&e, &raw.w[4 * rr], 8);
-        __builtin_memcpy(&o, &raw.w[4 * rr + 2], 8);
+        double lo, hi;
+        __builtin_memcpy(&lo, &raw.w[4 * rr], 8);
+        __builtin_memcpy(&hi, &raw.w[4 * rr + 2], 8);
+        e = ls.she ? hi : lo;
+        o = ls.she ? lo : hi;
     } else {
-        const int sh = SRC == KHG_SRC_Y ? 8 : 16;  // byte distance of the pair's second sample
         const uint32_t r = raw.w[3 * rr], g = raw.w[3 * rr + 1], b = raw.w[3 * rr + 2];
-        const double R0 = (double)(r & 255u), G0 = (double)(g & 255u), B0 = (double)(b & 255u);
-        const double R1 = (double)((r >> sh) & 255u), G1 = (double)((g >> sh) & 255u), B1 = (double)((b >> sh) & 255u);
+        const double R0 = (double)((r >> ls.she) & 255u), G0 = (double)((g >> ls.she) & 255u),
+                     B0 = (double)((b >> ls.she) & 255u);
+        const double R1 = (double)((r >> ls.sho) & 255u), G1 = (double)((g >> ls.sho) & 255u),
+                     B1 = (double)((b >> ls.sho) & 255u);
         if (SRC == KHG_SRC_Y) {
             e = R0 * 0.299 + G0 * 0.587 + B0 * 0.114;
             o = R1 * 0.299 + G1 * 0.587 + B1 * 0.114;
@@ -233,7 +285,8 @@ KHG_DEV void khg_fwd_samples(const KhgFwdRaw<SRC>& raw, int rr, int n, double& e
 
 // Per-thread tally of the symbols -1, 0, +1, which make up almost all detail-band symbols: counting them
 // in a register keeps 64 lanes from hammering one LDS word.  Bits 0-23: three 8-bit counters (a lane emits at most
-// four symbols per row pair of a segment); bits 24-29: one `seen` bit per (symbol, output stream).
+// four symbols per row pair of a segment), symbol q in byte 1 - q; bits 24-29: one `seen` bit per (symbol, output
+// stream), symbol q of stream t at bit 24 + 3 t + q + 1.  Both layouts make a symbol's word one instruction.
 // A lane's raster indices rise within each of its two output streams (rows k: low-half column, then high-half
 // column; rows hh+k: the same), so only the first hit of a symbol in a stream can lower the workgroup's
 // first-appearance index: one LDS atomic per bit, ever.
@@ -265,18 +318,24 @@ KHG_DEV int khg_quant_divide(const KhgFwdArgs& a, const KhgFwdPlane& pl, double 
     return (int)n;
 }
 
-// Tally word of a hot symbol (q in -1..1) in output stream `stream`: its 8-bit counter's unit, and its seen bit.
-KHG_DEV uint32_t khg_hot_unit(uint32_t q1) { return 1u << ((8u * q1) & 31u); }
-KHG_DEV uint32_t khg_hot_seen(uint32_t q1, int stream) { return 1u << ((24u + 2u * q1 + (uint32_t)stream) & 31u); }
+// Tally words of a hot symbol q = q1 - 1 in -1..1: its 8-bit counter's unit, and its seen bit in output stream
+// `stream`.  For other q1 the results are meaningless (and unused).
+#ifndef KHG_SIM
+KHG_DEV uint32_t khg_hot_unit(uint32_t q1) { return __builtin_amdgcn_alignbyte(0u, 0x10000u, q1); }  // 0x10000 >> 8 (q1 & 3)
+#else
+KHG_DEV uint32_t khg_hot_unit(uint32_t q1) { return 0x10000u >> (8u * (q1 & 3u)); }
+#endif
+KHG_DEV uint32_t khg_hot_seen(uint32_t q1, int stream) { return (1u << (24 + 3 * stream)) << (q1 & 31u); }
 
-// Count one symbol that the straight-line path could not finish: a hot symbol's first appearance in its stream
-// (its unit was added already), or any other symbol.  Returns the symbol to store (0 when out of range).
+// Count one symbol of a row pair that the straight-line path could not finish (it holds a symbol other than -1, 0,
+// +1, or the first appearance of one of those in its stream).  Returns the symbol to store (0 when out of range).
 template <int LHIST>
 KHG_DEV int khg_count_rare(const KhgFwdArgs& a, const KhgFwdPlane& pl, uint32_t* lcnt, uint32_t* lfirst, KhgHot& hot, int q,
                            int stream, uint32_t raster)
 {
     const uint32_t q1 = (uint32_t)(q + 1);
     if (q1 <= 2u) {
+        hot += khg_hot_unit(q1);
         const uint32_t bit = khg_hot_seen(q1, stream);
         if (!(hot & bit)) {
             hot |= bit;
@@ -325,19 +384,17 @@ KHG_DEV void khg_quant_emit(const KhgFwdArgs& a, const KhgFwdPlane& pl, uint32_t
             if (!khg_quant_try(c[i], rd[i], &qi)) q[i] = khg_quant_divide(a, pl, c[i], band[i], x[i], y[i]);
         }
     }
-    uint32_t units = 0, seen = 0;
-    bool allhot = true;
+    uint32_t units = 0, seen = 0, top = 0;
     KHG_UNROLL
     for (int i = 0; i < NS; ++i) {
         const uint32_t q1 = (uint32_t)(q[i] + 1);
-        const bool h = q1 <= 2u;
-        units += h ? khg_hot_unit(q1) : 0u;
-        seen |= h ? khg_hot_seen(q1, stream[i]) : 0u;
-        allhot = allhot && h;
+        top = q1 > top ? q1 : top;
+        units += khg_hot_unit(q1);
+        seen |= khg_hot_seen(q1, stream[i]);
     }
-    const bool fresh = (seen & ~hot) != 0;
-    hot += units;
-    if (!allhot || fresh) {
+    if (top <= 2u && (seen & ~hot) == 0) {  // all of them -1, 0 or +1 and seen in their streams before
+        hot += units;
+    } else {
         KHG_UNROLL
         for (int i = 0; i < NS; ++i)
             q[i] = khg_count_rare<LHIST>(a, pl, lcnt, lfirst, hot, q[i], stream[i], (so + boff[i]) >> 1);
@@ -404,19 +461,17 @@ KHG_DEV void khg_fwd_wg_body(const KhgFwdArgs& a, const KhgFwdPlane* pls, int wg
     const KhgFwdPlane& g = pls[0];  // geometry (shared by the NP planes)
     const int swg = wgl % g.nstrip_wg, seg = wgl / g.nstrip_wg;
     const int np = g.pw / 2, hh = g.ph / 2, hw = g.pw / 2;
-    const int nstrips = (np + KHG_STRIP_PAIRS - 1) / KHG_STRIP_PAIRS;
-    const int r0 = g.row_begin + seg * g.seg_rows;
-    const int r1 = (r0 + g.seg_rows < g.row_end) ? r0 + g.seg_rows : g.row_end;
+    int r0, r1;
+    khg_segment_rows(g.row_begin, g.row_end, g.nseg, seg, &r0, &r1);
     const int k0 = r0 / 2, k1 = r1 / 2;
-    const int P0 = khg_strip_first_pair(swg * KHG_WG_STRIPS, np);  // first pair of the workgroup
+    const int P0 = KHG_STRIP_PAIRS * KHG_WG_STRIPS * swg;  // first output pair of the workgroup
 
     KhgLift colL[NP][KHG_NSLOT(256)], colH[NP][KHG_NSLOT(256)];
     KhgHot hots[NP][KHG_NSLOT(256)];
     KhgFwdRaw<SRC> raws[KHG_NSLOT(256)];
-    int pairs[KHG_NSLOT(256)];     // pair held by this lane
-    uint32_t cols[KHG_NSLOT(256)]; // its column offset in the source
-    int flags[KHG_NSLOT(256)];     // bit 0: lane outputs its pair; bit 1: holds the plane's first pair; bit 2: its last
-    int edges[KHG_NSLOT(256)];     // wave-uniform: bit 1 / bit 2: a lane of this wave holds the first / last pair
+    KhgLaneSrc lsrc[KHG_NSLOT(256)];
+    int pairs[KHG_NSLOT(256)];     // the lane's pair, clamped to the strip's output pairs
+    bool outl[KHG_NSLOT(256)];     // the lane outputs its pair
     uint32_t symo[KHG_NSLOT(256)], llo[KHG_NSLOT(256)];  // byte offsets of (k, pair) in the symbol plane / LL buffer
     // values of the row pass that cross an exchange: [row a / b][plane]
     double E[2][NP][KHG_NSLOT(256)], O[2][NP][KHG_NSLOT(256)], D1[2][NP][KHG_NSLOT(256)], S1[2][NP][KHG_NSLOT(256)],
@@ -426,13 +481,12 @@ KHG_DEV void khg_fwd_wg_body(const KhgFwdArgs& a, const KhgFwdPlane* pls, int wg
     {
         if (a.prof && tid == 0) khg_atomic_max64(&a.prof->prof_not_start, ~khg_clock());
         const int lane = tid & 63, s = swg * KHG_WG_STRIPS + KHG_UNIFORM(tid >> 6);
-        const int p0 = khg_strip_first_pair(s, np);
-        const int p = p0 + lane;
+        // strip s outputs pairs 60 s .. 60 s + 59 (those inside the plane); its lanes hold pairs 60 s - 2 .. 60 s + 61
         const int v0 = KHG_STRIP_PAIRS * s, v1 = v0 + KHG_STRIP_PAIRS < np ? v0 + KHG_STRIP_PAIRS : np;
-        pairs[KHG_SLOT] = p < np ? p : np - 1;  // lanes beyond a narrow plane repeat its last pair (never output)
-        // a wave beyond the last strip repeats the last strip's loads and arithmetic without output
-        flags[KHG_SLOT] = (s < nstrips && p >= v0 && p < v1 ? 1 : 0) | (p == 0 ? 2 : 0) | (p == np - 1 ? 4 : 0);
-        edges[KHG_SLOT] = (p0 == 0 ? 2 : 0) | (p0 + KHG_LANES >= np ? 4 : 0);
+        const int p = v0 - 2 + lane;
+        outl[KHG_SLOT] = p >= v0 && p < v1;  // a wave beyond the last strip loads and computes without output
+        pairs[KHG_SLOT] = p < v0 ? v0 : (p > v0 + KHG_STRIP_PAIRS - 1 ? v0 + KHG_STRIP_PAIRS - 1 : p);
+        lsrc[KHG_SLOT] = khg_fwd_lane_src<SRC>(p, g.pw);
         // the first trip finishes row pair k0 - 4 (nothing is stored before k0; the offsets just run along)
         symo[KHG_SLOT] = 2u * ((uint32_t)(k0 - 4) * (uint32_t)g.sym_pitch + (uint32_t)pairs[KHG_SLOT]);
         llo[KHG_SLOT] = 8u * ((uint32_t)(k0 - 4) * (uint32_t)g.ll_pitch + (uint32_t)pairs[KHG_SLOT]);
@@ -443,9 +497,9 @@ KHG_DEV void khg_fwd_wg_body(const KhgFwdArgs& a, const KhgFwdPlane* pls, int wg
             hots[n][KHG_SLOT] = 0;
         }
         // rows of the first trip
-        cols[KHG_SLOT] = (SRC == KHG_SRC_C ? 4u : 2u) * (uint32_t)pairs[KHG_SLOT];
-        khg_fwd_fetch<SRC>(a, g, raws[KHG_SLOT], khg_fwd_row_offset<SRC>(a, g, khg_reflect(2 * (k0 - 2), g.ph)),
-                           khg_fwd_row_offset<SRC>(a, g, khg_reflect(2 * (k0 - 2) + 1, g.ph)), cols[KHG_SLOT]);
+        uint32_t foa, fob;
+        khg_fwd_row_offsets<SRC>(a, g, k0 - 2, foa, fob);
+        khg_fwd_fetch<SRC>(a, g, raws[KHG_SLOT], foa, fob, lsrc[KHG_SLOT].col);
         for (int n = 0; n < NP; ++n)
             for (int i = tid; i < SM::LHIST; i += 256) {
                 sh.cnt[n][i] = 0;
@@ -453,7 +507,7 @@ KHG_DEV void khg_fwd_wg_body(const KhgFwdArgs& a, const KhgFwdPlane* pls, int wg
             }
         // The divisor depends on the band and on x + y only (Compress.h:215-218); pair P0 + i at row pair k sits
         // on diagonal u = i + (k - k0) of each band this workgroup emits.
-        const int nu = KHG_WG_STRIPS * KHG_STRIP_PAIRS + 4 + (k1 - k0);
+        const int nu = KHG_WG_STRIPS * KHG_STRIP_PAIRS + (k1 - k0);
         for (int e = tid; e < SM::NBAND * nu; e += 256) {
             int s2 = e / nu, u = e - s2 * nu;
             int band = LEVEL == 1 ? 4 + s2 : s2;
@@ -467,19 +521,19 @@ KHG_DEV void khg_fwd_wg_body(const KhgFwdArgs& a, const KhgFwdPlane* pls, int wg
     // Row pairs k0-2 .. k1+1 are fed; the column pipeline hands back pair j-2 when pair j goes in.
     for (int j = k0 - 2; j <= k1 + 1; ++j) {
         // source rows of the next trip (the same for every thread)
-        const uint32_t noa = KHG_UNIFORM(khg_fwd_row_offset<SRC>(a, g, khg_reflect(2 * (j + 1), g.ph)));
-        const uint32_t nob = KHG_UNIFORM(khg_fwd_row_offset<SRC>(a, g, khg_reflect(2 * (j + 1) + 1, g.ph)));
+        uint32_t noa, nob;
+        khg_fwd_row_offsets<SRC>(a, g, j + 1, noa, nob);
         KHG_FOR_THREADS(256)
         {
             KHG_UNROLL
             for (int rr = 0; rr < 2; ++rr)
                 KHG_UNROLL
                 for (int n = 0; n < NP; ++n)
-                    khg_fwd_samples<SRC>(raws[KHG_SLOT], rr, n, E[rr][n][KHG_SLOT], O[rr][n][KHG_SLOT]);
+                    khg_fwd_samples<SRC>(raws[KHG_SLOT], lsrc[KHG_SLOT], rr, n, E[rr][n][KHG_SLOT], O[rr][n][KHG_SLOT]);
             // next trip's rows: in flight during this trip's arithmetic (unconditional, also after the last
             // trip, where the rows are reflected back into the plane and the loads are simply not used: a
             // condition here would make the loads land in other registers and cost a wait and copies per trip)
-            khg_fwd_fetch<SRC>(a, g, raws[KHG_SLOT], noa, nob, cols[KHG_SLOT]);
+            khg_fwd_fetch<SRC>(a, g, raws[KHG_SLOT], noa, nob, lsrc[KHG_SLOT].col);
         }
         // predict 1: d1[p] = o[p] + P1 * (e[p] + e[p+1])
         for (int rr = 0; rr < 2; ++rr)
@@ -489,13 +543,8 @@ KHG_DEV void khg_fwd_wg_body(const KhgFwdArgs& a, const KhgFwdPlane* pls, int wg
             KHG_UNROLL
             for (int rr = 0; rr < 2; ++rr)
                 KHG_UNROLL
-                for (int n = 0; n < NP; ++n) {
-                    double en = X[rr][n][KHG_SLOT];
-                    if (edges[KHG_SLOT] & 4) {  // DWT.h:18: x[n-1] += 2*a*x[n-2]
-                        if (flags[KHG_SLOT] & 4) en = E[rr][n][KHG_SLOT];
-                    }
-                    D1[rr][n][KHG_SLOT] = O[rr][n][KHG_SLOT] + KHG_P1 * (E[rr][n][KHG_SLOT] + en);
-                }
+                for (int n = 0; n < NP; ++n)
+                    D1[rr][n][KHG_SLOT] = O[rr][n][KHG_SLOT] + KHG_P1 * (E[rr][n][KHG_SLOT] + X[rr][n][KHG_SLOT]);
         }
         // update 1: s1[p] = e[p] + U1 * (d1[p-1] + d1[p])
         for (int rr = 0; rr < 2; ++rr)
@@ -505,13 +554,8 @@ KHG_DEV void khg_fwd_wg_body(const KhgFwdArgs& a, const KhgFwdPlane* pls, int wg
             KHG_UNROLL
             for (int rr = 0; rr < 2; ++rr)
                 KHG_UNROLL
-                for (int n = 0; n < NP; ++n) {
-                    double dp = X[rr][n][KHG_SLOT];
-                    if (edges[KHG_SLOT] & 2) {  // DWT.h:26: x[0] += 2*a*x[1]
-                        if (flags[KHG_SLOT] & 2) dp = D1[rr][n][KHG_SLOT];
-                    }
-                    S1[rr][n][KHG_SLOT] = E[rr][n][KHG_SLOT] + KHG_U1 * (dp + D1[rr][n][KHG_SLOT]);
-                }
+                for (int n = 0; n < NP; ++n)
+                    S1[rr][n][KHG_SLOT] = E[rr][n][KHG_SLOT] + KHG_U1 * (X[rr][n][KHG_SLOT] + D1[rr][n][KHG_SLOT]);
         }
         // predict 2: d2[p] = d1[p] + P2 * (s1[p] + s1[p+1])
         for (int rr = 0; rr < 2; ++rr)
@@ -521,13 +565,8 @@ KHG_DEV void khg_fwd_wg_body(const KhgFwdArgs& a, const KhgFwdPlane* pls, int wg
             KHG_UNROLL
             for (int rr = 0; rr < 2; ++rr)
                 KHG_UNROLL
-                for (int n = 0; n < NP; ++n) {
-                    double sn = X[rr][n][KHG_SLOT];
-                    if (edges[KHG_SLOT] & 4) {  // DWT.h:34
-                        if (flags[KHG_SLOT] & 4) sn = S1[rr][n][KHG_SLOT];
-                    }
-                    D2[rr][n][KHG_SLOT] = D1[rr][n][KHG_SLOT] + KHG_P2 * (S1[rr][n][KHG_SLOT] + sn);
-                }
+                for (int n = 0; n < NP; ++n)
+                    D2[rr][n][KHG_SLOT] = D1[rr][n][KHG_SLOT] + KHG_P2 * (S1[rr][n][KHG_SLOT] + X[rr][n][KHG_SLOT]);
         }
         // update 2: s2[p] = s1[p] + U2 * (d2[p-1] + d2[p]); scale; columns
         for (int rr = 0; rr < 2; ++rr)
@@ -535,7 +574,7 @@ KHG_DEV void khg_fwd_wg_body(const KhgFwdArgs& a, const KhgFwdPlane* pls, int wg
         KHG_FOR_THREADS(256)
         {
             const int k = j - 2;
-            const bool out = (flags[KHG_SLOT] & 1) && k >= k0 && k < k1;
+            const bool out = outl[KHG_SLOT] && k >= k0 && k < k1;
             const int pair = pairs[KHG_SLOT];
             const double* rd = &sh.rdiv[KHG_RD_PAD + (pair - P0) + (k - k0)];
             double rdv[SM::NBAND];
@@ -547,11 +586,7 @@ KHG_DEV void khg_fwd_wg_body(const KhgFwdArgs& a, const KhgFwdPlane* pls, int wg
                 double lo[2], hi[2];
                 KHG_UNROLL
                 for (int rr = 0; rr < 2; ++rr) {
-                    double dp = X[rr][n][KHG_SLOT];
-                    if (edges[KHG_SLOT] & 2) {  // DWT.h:42
-                        if (flags[KHG_SLOT] & 2) dp = D2[rr][n][KHG_SLOT];
-                    }
-                    const double s2 = S1[rr][n][KHG_SLOT] + KHG_U2 * (dp + D2[rr][n][KHG_SLOT]);
+                    const double s2 = S1[rr][n][KHG_SLOT] + KHG_U2 * (X[rr][n][KHG_SLOT] + D2[rr][n][KHG_SLOT]);
                     lo[rr] = khg_fwd_scale_even(s2);
                     hi[rr] = khg_fwd_scale_odd(D2[rr][n][KHG_SLOT]);
                 }
@@ -571,9 +606,9 @@ KHG_DEV void khg_fwd_wg_body(const KhgFwdArgs& a, const KhgFwdPlane* pls, int wg
     {
         for (int n = 0; n < NP; ++n) {
             const KhgHot hot = hots[n][KHG_SLOT];
-            for (int v = 0; v < 3; ++v) {
+            for (int v = 0; v < 3; ++v) {  // byte v counts symbol 1 - v
                 uint32_t c = (hot >> (8 * v)) & 0xFFu;
-                if (c) khg_lds_add(&sh.cnt[n][SM::LHIST_BIAS - 1 + v], c);
+                if (c) khg_lds_add(&sh.cnt[n][SM::LHIST_BIAS + 1 - v], c);
             }
         }
     }
@@ -596,10 +631,22 @@ KHG_DEV void khg_fwd_wg_body(const KhgFwdArgs& a, const KhgFwdPlane* pls, int wg
 // Launch kinds.
 enum { KHG_FWD_RGB = 0, KHG_FWD_PLANES1 = 1, KHG_FWD_PLANES2 = 2 };
 
+#if defined(KHG_TIMING) && !defined(KHG_SIM)
+// developer build: per-workgroup start / end stamps (100 MHz) and hardware id of the last forward launch
+__device__ uint32_t khg_dbg_fwd[4 * 8192];
+#define KHG_FWD_STAMP(wg, slot, v) \
+    if (threadIdx.x == 0 && (wg) < 8192) khg_dbg_fwd[4 * (wg) + (slot)] = (v)
+#else
+#define KHG_FWD_STAMP(wg, slot, v)
+#endif
+
 // Workgroup `wg` of a launch: which plane it belongs to, and its body.
 template <int KIND>
 KHG_DEV void khg_fwd_launch_body(const KhgFwdArgs& a, int wg, KhgFwdSmemAny& sh)
 {
+    KHG_FWD_STAMP(wg, 0, (uint32_t)wall_clock64());
+    KHG_FWD_STAMP(wg, 2, __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)));  // HW_ID
+    KHG_FWD_STAMP(wg, 3, __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)));  // XCC_ID
     if constexpr (KIND == KHG_FWD_RGB) {
         if (a.nplanes < 2 || wg < a.pl[1].wg0) khg_fwd_wg_body<KHG_SRC_Y, 1, 1>(a, &a.pl[0], wg, sh.y);
         else khg_fwd_wg_body<KHG_SRC_C, 1, 2>(a, &a.pl[1], wg - a.pl[1].wg0, sh.c);
@@ -609,4 +656,5 @@ KHG_DEV void khg_fwd_launch_body(const KhgFwdArgs& a, int wg, KhgFwdSmemAny& sh)
         if constexpr (KIND == KHG_FWD_PLANES1) khg_fwd_wg_body<KHG_SRC_PLANE, 1, 1>(a, &a.pl[p], wg - a.pl[p].wg0, sh.y);
         else khg_fwd_wg_body<KHG_SRC_PLANE, 2, 1>(a, &a.pl[p], wg - a.pl[p].wg0, sh.l2);
     }
+    KHG_FWD_STAMP(wg, 1, (uint32_t)wall_clock64());
 }

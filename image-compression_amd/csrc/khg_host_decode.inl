@@ -271,6 +271,11 @@ extern "C" int khg_psnr_dev(khg_ctx* c, const uint8_t* d_ir, const uint8_t* d_ig
 }
 
 #ifdef KHG_TIMING
+extern "C" int khg_debug_fwd(uint32_t* host, size_t words)
+{
+    if (words > 4 * 8192) words = 4 * 8192;
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(khg_dbg_fwd), words * 4) == hipSuccess ? 0 : KHG_ERR_HIP;
+}
 // Developer build only: the per-workgroup records of the last decode (timing stamps in pad_).
 extern "C" int khg_debug_blocks(khg_ctx* c, void* host, size_t bytes, uint32_t* blk0, uint32_t* nblocks)
 {

@@ -31,7 +31,7 @@ struct KhgInvPlane {
     double* dst;          // natural-order output, ph x pw (unused by the RGB variant)
     int dst_pitch;
     int row_begin, row_end;  // output rows this launch produces (even; the whole plane, or one tile's band)
-    int seg_rows;         // output rows per workgroup segment (even)
+    int seg_rows;         // output rows of the tallest workgroup segment (even; see khg_segment_rows)
     int nseg;
     int nstrip_wg;        // workgroups side by side (KHG_WG_STRIPS strips each)
     int wg0;              // first workgroup of this plane in the launch
@@ -141,8 +141,8 @@ KHG_DEV void khg_inv_wg_body(const KhgInvArgs& a, const KhgInvPlane& pl, int wgl
     const int swg = wgl % pl.nstrip_wg, seg = wgl / pl.nstrip_wg;
     const int np = pl.pw / 2, hh = pl.ph / 2, hw = pl.pw / 2;
     const int nstrips = (np + KHG_STRIP_PAIRS - 1) / KHG_STRIP_PAIRS;
-    const int r0 = pl.row_begin + seg * pl.seg_rows;
-    const int r1 = (r0 + pl.seg_rows < pl.row_end) ? r0 + pl.seg_rows : pl.row_end;
+    int r0, r1;
+    khg_segment_rows(pl.row_begin, pl.row_end, pl.nseg, seg, &r0, &r1);
     const int k0 = r0 / 2, k1 = r1 / 2;
     const int P0 = khg_strip_first_pair(swg * KHG_WG_STRIPS, np);  // first pair of the workgroup
     // packed rows this segment reads (reflections included) lie in [klo, klo + nk)

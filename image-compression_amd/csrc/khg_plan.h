@@ -210,44 +210,42 @@ static inline void khg_fwd_plane(KhgFwdPlane* pl, const KhgWorkspace& ws, int ro
 #endif
 
 // One group of planes of a transform launch that share a grid (Y alone, Cb with Cr, ...): pw columns, `span` rows
-// to transform, `weight` = cost per row relative to a single plane.  The planner fills in the rest.
+// to transform, `weight` = cost of one of its workgroups per row, relative to the other groups of the launch.  The
+// planner fills in the rest.
 struct KhgGridGroup {
     int pw, span, weight;
     int seg_rows, nseg, nstrip_wg, wg0;
 };
 
-// Grid of a transform launch.  A workgroup walks a segment of its rows plus 8 warm-up rows, so segments should be as
-// tall as the chip allows: the segment heights are the ones at which every group's workgroups carry about the same
-// work and all of them together just fit the chip at once (`slots`), within 16 .. KHG_MAX_SEG_ROWS rows.
+enum { KHG_SEG_WARMUP = 8 };  // rows a workgroup transforms before its segment's first output row
+
+// Grid of a transform launch.  A workgroup walks a segment of its rows plus KHG_SEG_WARMUP rows, so segments should
+// be as tall as the chip allows; every workgroup of the launch is resident at once (`slots`) and the launch lasts as
+// long as its slowest one, so the segment heights are the ones at which every group's workgroups cost the same,
+// (rows + warm-up) x weight, and all of them together just fit the chip, within 16 .. KHG_MAX_SEG_ROWS rows.
 // Returns the number of workgroups.
 static inline int khg_plan_groups(KhgGridGroup* g, int ngroup, int slots)
 {
-    long total = 0;
     for (int i = 0; i < ngroup; ++i) {
         const int nstrips = (g[i].pw / 2 + KHG_STRIP_PAIRS - 1) / KHG_STRIP_PAIRS;
         g[i].nstrip_wg = (nstrips + KHG_WG_STRIPS - 1) / KHG_WG_STRIPS;
-        total += (long)g[i].nstrip_wg * g[i].span * g[i].weight;
     }
-    long T = (total + slots - 1) / slots;  // weighted rows per workgroup
-    for (;;) {
+    for (long T = 1;; ++T) {  // cost per workgroup
         long wgs = 0;
         bool all_max = true;
         for (int i = 0; i < ngroup; ++i) {
             const int span = g[i].span;
-            int seg = (int)((T / g[i].weight + 1) & ~1L);
+            int seg = (int)((T / g[i].weight - KHG_SEG_WARMUP) & ~1L);
             if (seg < 16) seg = 16;
             if (seg > KHG_MAX_SEG_ROWS) seg = KHG_MAX_SEG_ROWS;
             if (seg > span) seg = span;
             if (seg < KHG_MAX_SEG_ROWS && seg < span) all_max = false;  // this group could still take taller segments
-            int nseg = (span + seg - 1) / seg;
-            seg = ((span + nseg - 1) / nseg + 1) & ~1;  // equal segments
-            nseg = (span + seg - 1) / seg;
-            g[i].seg_rows = seg;
+            const int nseg = (span + seg - 1) / seg;
             g[i].nseg = nseg;
+            g[i].seg_rows = 2 * ((span / 2 + nseg - 1) / nseg);  // the tallest of nseg even shares
             wgs += (long)g[i].nstrip_wg * nseg;
         }
-        if (wgs <= slots || all_max || T > 4L * KHG_MAX_SEG_ROWS) break;
-        T += 2;
+        if (wgs <= slots || all_max) break;
     }
     int wg = 0;
     for (int i = 0; i < ngroup; ++i) {
@@ -294,7 +292,8 @@ static inline KhgFwdArgs khg_fwd_args_rgb(const KhgWorkspace& ws, const uint8_t*
     KhgFwdArgs a;
     khg_fwd_args_common(&a, ws, r, g, b, rows, cols, lvl, tile);
     for (int p = 0; p < 3; ++p) khg_fwd_plane(&a.pl[p], ws, rows, cols, lvl, p, 1, coef ? coef[p] : nullptr, tile, nullptr);
-    const int first[2] = {0, 1}, count[2] = {1, 2}, weight[2] = {1, 2};
+    // a row of a chroma workgroup (Cb and Cr together, half the strips' pixels each) costs 2.25 luma rows (measured)
+    const int first[2] = {0, 1}, count[2] = {1, 2}, weight[2] = {4, 9};
     a.nplanes = luma_only ? 1 : 3;
     khg_fwd_plan_grid(&a, luma_only ? 1 : 2, first, count, weight);
     return a;
