@@ -22,7 +22,11 @@
 #pragma once
 #include "khg_common.h"
 
-enum { KHG_SRC_Y = 0, KHG_SRC_C = 1, KHG_SRC_PLANE = 3 };
+// Sources of a transform: planar u8 R, G, B -> Y / -> Cb and Cr; an f64 plane; and the pixel array of a 24-bit BMP
+// (B, G, R bytes per pixel, rows bottom-up, KhuGleSignal.cpp:264-272) -> Y / -> Cb and Cr.
+enum { KHG_SRC_Y = 0, KHG_SRC_C = 1, KHG_SRC_PLANE = 3, KHG_SRC_Y_BGR = 4, KHG_SRC_C_BGR = 5 };
+#define KHG_SRC_IS_LUMA(SRC) ((SRC) == KHG_SRC_Y || (SRC) == KHG_SRC_Y_BGR)
+#define KHG_SRC_IS_BGR(SRC) ((SRC) == KHG_SRC_Y_BGR || (SRC) == KHG_SRC_C_BGR)
 
 enum {
     KHG_LANES = 64,
@@ -58,8 +62,9 @@ struct KhgFwdPlane {
 };
 
 struct KhgFwdArgs {
-    const uint8_t *r, *g, *b;  // full-resolution RGB planes, or a band of their rows
-    int img_w;                 // their row pitch (image columns)
+    const uint8_t *r, *g, *b;  // full-resolution RGB planes, or a band of their rows; BGR sources: r = the pixel array
+    int img_w;                 // image columns (the planes' row pitch)
+    int bgr_stride;            // BGR sources: bytes per pixel row (3 * img_w rounded up to a multiple of 4)
     int in_row0;               // image row held by the first row of r/g/b (0 for a whole image)
     int in_rows;               // image rows r/g/b hold
     int* status;
@@ -171,6 +176,7 @@ template <int SRC>
 struct KhgFwdRaw {
     // Y: r, g, b of row a, then of row b, two pixels per 16-bit load.  C: r, g, b of the two pixel rows, four
     // pixels per 32-bit load (bytes 0 and 2 are the two chroma sites).  PLANE: the pair of row a, the pair of row b.
+    // Y_BGR: the six bytes of two pixels as three 16-bit loads per row.  C_BGR: two 32-bit loads per row, one per site.
     uint32_t w[SRC == KHG_SRC_PLANE ? 8 : 6];
 };
 
@@ -183,7 +189,9 @@ KHG_DEV uint32_t khg_fwd_row_offset(const KhgFwdArgs& a, const KhgFwdPlane& pl, 
 {
     if (SRC == KHG_SRC_PLANE) return (uint32_t)y * (uint32_t)pl.src_pitch;
     // chroma site (y, x) reads the pixel at (2y, 2x): Colorspace.h:16-21
-    return (uint32_t)khg_band_row(a, SRC == KHG_SRC_Y ? y : 2 * y) * (uint32_t)a.img_w;
+    const int r = khg_band_row(a, KHG_SRC_IS_LUMA(SRC) ? y : 2 * y);
+    if (KHG_SRC_IS_BGR(SRC)) return (uint32_t)(a.in_rows - 1 - r) * (uint32_t)a.bgr_stride;  // the file's rows run bottom-up
+    return (uint32_t)r * (uint32_t)a.img_w;
 }
 
 // Offsets of the two source rows of row pair j (plane rows 2j and 2j+1, reflected into the plane).  Nearly every
@@ -198,11 +206,16 @@ KHG_DEV void khg_fwd_row_offsets(const KhgFwdArgs& a, const KhgFwdPlane& pl, int
             ob = oa + (uint32_t)KHG_UNIFORM(pl.src_pitch);
             return;
         }
-        const int f = SRC == KHG_SRC_Y ? 1 : 2;
+        const int f = KHG_SRC_IS_LUMA(SRC) ? 1 : 2;
         const int ra = f * ya - KHG_UNIFORM(a.in_row0), rb = ra + f;
         if (ra >= 0 && rb < KHG_UNIFORM(a.in_rows)) {
-            oa = (uint32_t)ra * (uint32_t)KHG_UNIFORM(a.img_w);
-            ob = (uint32_t)rb * (uint32_t)KHG_UNIFORM(a.img_w);
+            if (KHG_SRC_IS_BGR(SRC)) {
+                oa = (uint32_t)(KHG_UNIFORM(a.in_rows) - 1 - ra) * (uint32_t)KHG_UNIFORM(a.bgr_stride);
+                ob = (uint32_t)(KHG_UNIFORM(a.in_rows) - 1 - rb) * (uint32_t)KHG_UNIFORM(a.bgr_stride);
+            } else {
+                oa = (uint32_t)ra * (uint32_t)KHG_UNIFORM(a.img_w);
+                ob = (uint32_t)rb * (uint32_t)KHG_UNIFORM(a.img_w);
+            }
             return;
         }
     }
@@ -214,9 +227,9 @@ KHG_DEV void khg_fwd_row_offsets(const KhgFwdArgs& a, const KhgFwdPlane& pl, int
 // outside the plane, and anywhere for lanes beyond the last strip, whose loads are not used).  The two reflected
 // columns are always neighbours; `col` is the lower one and `swap` says that it holds the odd sample.
 struct KhgLaneSrc {
-    uint32_t col;  // column offset of the load in elements of the source (pixels for RGB)
-    uint32_t she;  // RGB: bit position of the even sample's byte in the loaded word; planes: nonzero = swapped
-    uint32_t sho;  // RGB: bit position of the odd sample's byte
+    uint32_t col;  // column offset of the load in elements of the source (planar RGB: pixels; BGR: bytes)
+    uint32_t she;  // planar RGB: bit position of the even sample's byte in the loaded word; others: nonzero = swapped
+    uint32_t sho;  // planar RGB: bit position of the odd sample's byte
 };
 
 template <int SRC>
@@ -227,7 +240,7 @@ KHG_DEV KhgLaneSrc khg_fwd_lane_src(int p, int pw)
     const uint32_t lo = (uint32_t)(swap ? oc : ec);
     const uint32_t sh = SRC == KHG_SRC_Y ? 8u : 16u;  // distance of the pair's samples in the word: chroma sites are
     KhgLaneSrc l;                                     // every second pixel (Colorspace.h:16-21)
-    l.col = SRC == KHG_SRC_C ? 2u * lo : lo;
+    l.col = SRC == KHG_SRC_C ? 2u * lo : SRC == KHG_SRC_Y_BGR ? 3u * lo : SRC == KHG_SRC_C_BGR ? 6u * lo : lo;
     l.she = swap ? sh : 0u;
     l.sho = swap ? 0u : sh;
     return l;
@@ -247,6 +260,12 @@ KHG_DEV void khg_fwd_fetch(const KhgFwdArgs& a, const KhgFwdPlane& pl, KhgFwdRaw
     } else if constexpr (SRC == KHG_SRC_Y) {
         raw.w[0] = khg_ld16(a.r + oa); raw.w[1] = khg_ld16(a.g + oa); raw.w[2] = khg_ld16(a.b + oa);
         raw.w[3] = khg_ld16(a.r + ob); raw.w[4] = khg_ld16(a.g + ob); raw.w[5] = khg_ld16(a.b + ob);
+    } else if constexpr (SRC == KHG_SRC_Y_BGR) {  // B G R B G R of two neighbouring pixels
+        raw.w[0] = khg_ld16(a.r + oa); raw.w[1] = khg_ld16(a.r + oa + 2); raw.w[2] = khg_ld16(a.r + oa + 4);
+        raw.w[3] = khg_ld16(a.r + ob); raw.w[4] = khg_ld16(a.r + ob + 2); raw.w[5] = khg_ld16(a.r + ob + 4);
+    } else if constexpr (SRC == KHG_SRC_C_BGR) {  // B G R (and one more byte) of two pixels two columns apart
+        raw.w[0] = khg_ld32(a.r + oa); raw.w[1] = khg_ld32(a.r + oa + 6);
+        raw.w[2] = khg_ld32(a.r + ob); raw.w[3] = khg_ld32(a.r + ob + 6);
     } else {
         raw.w[0] = khg_ld32(a.r + oa); raw.w[1] = khg_ld32(a.g + oa); raw.w[2] = khg_ld32(a.b + oa);
         raw.w[3] = khg_ld32(a.r + ob); raw.w[4] = khg_ld32(a.g + ob); raw.w[5] = khg_ld32(a.b + ob);
@@ -264,6 +283,31 @@ KHG_DEV void khg_fwd_samples(const KhgFwdRaw<SRC>& raw, const KhgLaneSrc& ls, in
         __builtin_memcpy(&hi, &raw.w[4 * rr + 2], 8);
         e = ls.she ? hi : lo;
         o = ls.she ? lo : hi;
+    } else if constexpr (KHG_SRC_IS_BGR(SRC)) {
+        uint32_t pa, pb;  // (B, G, R) of the lower and of the upper pixel in bits 0-23
+        if (SRC == KHG_SRC_Y_BGR) {
+            const uint32_t w0 = raw.w[3 * rr], w1 = raw.w[3 * rr + 1], w2 = raw.w[3 * rr + 2];
+            pa = w0 | (w1 << 16);
+            pb = (w1 >> 8) | (w2 << 8);
+        } else {
+            pa = raw.w[2 * rr];
+            pb = raw.w[2 * rr + 1];
+        }
+        const double B0 = (double)(pa & 255u), G0 = (double)((pa >> 8) & 255u), R0 = (double)((pa >> 16) & 255u);
+        const double B1 = (double)(pb & 255u), G1 = (double)((pb >> 8) & 255u), R1 = (double)((pb >> 16) & 255u);
+        double va, vb;
+        if (SRC == KHG_SRC_Y_BGR) {
+            va = R0 * 0.299 + G0 * 0.587 + B0 * 0.114;
+            vb = R1 * 0.299 + G1 * 0.587 + B1 * 0.114;
+        } else if (n == 0) {
+            va = R0 * -0.16874 + G0 * -0.33126 + B0 * 0.5;
+            vb = R1 * -0.16874 + G1 * -0.33126 + B1 * 0.5;
+        } else {
+            va = R0 * 0.5 + G0 * -0.41869 + B0 * -0.08131;
+            vb = R1 * 0.5 + G1 * -0.41869 + B1 * -0.08131;
+        }
+        e = ls.she ? vb : va;
+        o = ls.she ? va : vb;
     } else {
         const uint32_t r = raw.w[3 * rr], g = raw.w[3 * rr + 1], b = raw.w[3 * rr + 2];
         const double R0 = (double)((r >> ls.she) & 255u), G0 = (double)((g >> ls.she) & 255u),
@@ -629,7 +673,7 @@ KHG_DEV void khg_fwd_wg_body(const KhgFwdArgs& a, const KhgFwdPlane* pls, int wg
 }
 
 // Launch kinds.
-enum { KHG_FWD_RGB = 0, KHG_FWD_PLANES1 = 1, KHG_FWD_PLANES2 = 2 };
+enum { KHG_FWD_RGB = 0, KHG_FWD_PLANES1 = 1, KHG_FWD_PLANES2 = 2, KHG_FWD_BGR = 3 };
 
 #if defined(KHG_TIMING) && !defined(KHG_SIM)
 // developer build: per-workgroup start / end stamps (100 MHz) and hardware id of the last forward launch
@@ -650,6 +694,9 @@ KHG_DEV void khg_fwd_launch_body(const KhgFwdArgs& a, int wg, KhgFwdSmemAny& sh)
     if constexpr (KIND == KHG_FWD_RGB) {
         if (a.nplanes < 2 || wg < a.pl[1].wg0) khg_fwd_wg_body<KHG_SRC_Y, 1, 1>(a, &a.pl[0], wg, sh.y);
         else khg_fwd_wg_body<KHG_SRC_C, 1, 2>(a, &a.pl[1], wg - a.pl[1].wg0, sh.c);
+    } else if constexpr (KIND == KHG_FWD_BGR) {
+        if (a.nplanes < 2 || wg < a.pl[1].wg0) khg_fwd_wg_body<KHG_SRC_Y_BGR, 1, 1>(a, &a.pl[0], wg, sh.y);
+        else khg_fwd_wg_body<KHG_SRC_C_BGR, 1, 2>(a, &a.pl[1], wg - a.pl[1].wg0, sh.c);
     } else {
         int p = 0;
         while (p + 1 < a.nplanes && wg >= a.pl[p + 1].wg0) ++p;

@@ -138,6 +138,7 @@ extern "C" int khg_batch_encode(khg_batch* b, int n, const uint8_t* const* rgb, 
         if (rc == KHG_OK)
             rc = khg_encode_dev(s.ctx, s.d_rgb, s.d_rgb + np, s.d_rgb + 2 * np, rows, cols, lvl, s.d_comp, b->comp_cap, s.stream);
         if (rc != KHG_OK) {
+            (void)hipStreamSynchronize(s.stream);  // the H2D copy may still be reading the slot's staging buffer
             status[f] = rc;
             out_len[f] = 0;
             continue;
@@ -157,7 +158,9 @@ static void khg_batch_finish_decode(khg_batch* b, khg_batch_slot& s, uint8_t* co
     if (f < 0) return;
     s.frame = -1;
     int rc = khg_last_status(s.ctx);  // kernels done
-    if (rc == KHG_OK && hipEventSynchronize(s.copied) != hipSuccess) rc = KHG_ERR_HIP;  // D2H done
+    // the D2H copy was enqueued whatever the decode's status turns out to be: it must have finished before the
+    // slot's buffers (or the caller's) are touched again
+    if (hipEventSynchronize(s.copied) != hipSuccess && rc == KHG_OK) rc = KHG_ERR_HIP;
     if (rc == KHG_OK && !khg_is_pinned(rgb_out[f])) memcpy(rgb_out[f], s.h_rgb, 3 * (size_t)rows[f] * cols[f]);
     status[f] = rc;
 }
@@ -200,6 +203,9 @@ extern "C" int khg_batch_decode(khg_batch* b, int n, const uint8_t* const* comp,
                 rc = KHG_ERR_HIP;
         }
         if (rc != KHG_OK) {
+            // whatever was enqueued before the failure (the H2D copy, the decode) may still use the slot's buffers
+            (void)hipStreamSynchronize(s.stream);
+            (void)khg_last_status(s.ctx);  // and a decode that was enqueued leaves the context waiting for this call
             status[f] = rc;
             continue;
         }

@@ -42,7 +42,12 @@ static inline void khg_make_quant(int rows, int cols, int lvl, int chroma, KhgQu
     }
 }
 
-static inline int khg_dims_ok(int rows, int cols) { return rows > 0 && cols > 0 && rows % 8 == 0 && cols % 8 == 0; }
+// Image sizes the library takes: multiples of 8 (two DWT levels on 4:2:0 planes) with fewer than 2^31 pixels (raster
+// indices, plane offsets and the header's bit lengths are 32-bit).
+static inline int khg_dims_ok(int rows, int cols)
+{
+    return rows > 0 && cols > 0 && rows % 8 == 0 && cols % 8 == 0 && (long long)rows * cols < (1LL << 31);
+}
 
 // Device workspace of one context (all pointers into device memory, or host memory in the simulator).
 struct KhgWorkspace {
@@ -287,10 +292,11 @@ static inline void khg_fwd_args_common(KhgFwdArgs* a, const KhgWorkspace& ws, co
 // carry Cb and Cr together.  luma_only: just the luma workgroups (a measurement aid).
 static inline KhgFwdArgs khg_fwd_args_rgb(const KhgWorkspace& ws, const uint8_t* r, const uint8_t* g, const uint8_t* b,
                                           int rows, int cols, int lvl, double* const coef[3],
-                                          KhgTile tile = KhgTile{0, 1}, bool luma_only = false)
+                                          KhgTile tile = KhgTile{0, 1}, bool luma_only = false, int bgr_stride = 0)
 {
     KhgFwdArgs a;
     khg_fwd_args_common(&a, ws, r, g, b, rows, cols, lvl, tile);
+    a.bgr_stride = bgr_stride;  // nonzero: r is the pixel array of a 24-bit BMP (KHG_FWD_BGR launch)
     for (int p = 0; p < 3; ++p) khg_fwd_plane(&a.pl[p], ws, rows, cols, lvl, p, 1, coef ? coef[p] : nullptr, tile, nullptr);
     // a row of a chroma workgroup (Cb and Cr together, half the strips' pixels each) costs 2.25 luma rows (measured)
     const int first[2] = {0, 1}, count[2] = {1, 2}, weight[2] = {4, 9};

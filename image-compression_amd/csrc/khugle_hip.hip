@@ -382,18 +382,20 @@ static int khg_enqueue_entropy(khg_ctx* c, int rows, int cols, int lvl, uint8_t*
 }
 
 static int khg_enqueue_forward(khg_ctx* c, const uint8_t* r, const uint8_t* g, const uint8_t* b, int rows, int cols,
-                               int lvl, double* const coef[3], hipStream_t st, KhgTile tile = KhgTile{0, 1})
+                               int lvl, double* const coef[3], hipStream_t st, KhgTile tile = KhgTile{0, 1},
+                               int bgr_stride = 0)
 {
     KhgWorkspace& ws = c->ws;
     KHG_HIP(hipMemsetAsync(ws.hist_cnt, 0, 3 * KHG_NBINS * sizeof(uint32_t), st));
     KHG_HIP(hipMemsetAsync(ws.hist_first, 0xFF, 3 * KHG_NBINS * sizeof(uint32_t), st));
     KHG_HIP(hipMemsetAsync(ws.res, 0, sizeof(KhgResult), st));
-    KhgFwdArgs a = khg_fwd_args_rgb(ws, r, g, b, rows, cols, lvl, coef, tile);
+    KhgFwdArgs a = khg_fwd_args_rgb(ws, r, g, b, rows, cols, lvl, coef, tile, false, bgr_stride);
     if (c->prof_on) {
         KHG_HIP(hipEventRecord(c->prof_e0, st));
         a.prof = ws.res;
     }
-    khg_launch_fwd<KHG_FWD_RGB>(a, st);
+    if (bgr_stride) khg_launch_fwd<KHG_FWD_BGR>(a, st);
+    else khg_launch_fwd<KHG_FWD_RGB>(a, st);
     if (c->prof_on) {
         KHG_HIP(hipEventRecord(c->prof_e1, st));
         c->prof_pending = 1;
@@ -415,6 +417,23 @@ extern "C" int khg_encode_dev(khg_ctx* c, const uint8_t* d_r, const uint8_t* d_g
     KHG_HIP(hipSetDevice(c->device));
     if ((rc = khg_begin(c, st))) return rc;
     rc = khg_enqueue_forward(c, d_r, d_g, d_b, rows, cols, lvl, nullptr, st);
+    if (rc) return rc;
+    return khg_enqueue_entropy(c, rows, cols, lvl, d_out, cap, st);
+}
+
+extern "C" int khg_encode_bgr_dev(khg_ctx* c, const uint8_t* d_pixels, size_t stride, int rows, int cols, int lvl,
+                                  uint8_t* d_out, size_t cap, void* stream)
+{
+    int rc = khg_check_image(c, rows, cols);
+    if (rc) return rc;
+    if (lvl < 0 || lvl > 2) return KHG_ERR_DIMS;
+    if (!d_pixels || !d_out || ((uintptr_t)d_out & 3)) return KHG_ERR_ARG;
+    if (stride < 3 * (size_t)cols || stride * (size_t)rows >= ((size_t)1 << 32)) return KHG_ERR_DIMS;  // 32-bit byte offsets
+    if (cap < 40) return KHG_ERR_CAP;
+    hipStream_t st = (hipStream_t)stream;
+    KHG_HIP(hipSetDevice(c->device));
+    if ((rc = khg_begin(c, st))) return rc;
+    rc = khg_enqueue_forward(c, d_pixels, nullptr, nullptr, rows, cols, lvl, nullptr, st, KhgTile{0, 1}, (int)stride);
     if (rc) return rc;
     return khg_enqueue_entropy(c, rows, cols, lvl, d_out, cap, st);
 }

@@ -5,7 +5,7 @@ C ABI of include/khugle_hip.h; this package only moves buffers and mirrors the r
 calling sequence.  Importing the package does not load the library; using it does, and fails
 loudly when the library or a HIP device is missing.
 """
-from .bmp import read_bmp, write_bmp  # noqa: F401
+from .bmp import bmp24_pixels, read_bmp, write_bmp  # noqa: F401
 from .synth import synth_frame  # noqa: F401
 from .lib import KhgError, LIB_PATH, load  # noqa: F401
 from .codec import Codec, peek  # noqa: F401

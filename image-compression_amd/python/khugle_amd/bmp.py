@@ -47,6 +47,26 @@ def read_bmp(path):
     raise ValueError("%s: %d-bpp BMP not supported" % (path, bit_count))
 
 
+def bmp24_pixels(path):
+    """The pixel array of an uncompressed 24-bit BMP exactly as it lies in the file -- (bytes, stride, width, height),
+    B, G, R per pixel, rows bottom-up, `stride` bytes per row -- or None for any other kind of BMP.  This is what
+    Codec.encode_bgr_dev takes: ReadBmp's conversion loop (KhuGleSignal.cpp:264-272) then happens on the GPU."""
+    with open(path, "rb") as f:
+        data = f.read()
+    if data[:2] != b"BM":
+        raise ValueError("%s: not a BMP file" % path)
+    off_bits = struct.unpack_from("<I", data, 10)[0]
+    width, height = struct.unpack_from("<ii", data, 18)
+    bit_count = struct.unpack_from("<H", data, 28)[0]
+    compression = struct.unpack_from("<I", data, 30)[0]
+    if bit_count != 24 or compression != 0 or width <= 0 or height <= 0:
+        return None
+    stride = (width * 3 + 3) // 4 * 4
+    if off_bits + stride * height > len(data):
+        raise ValueError("%s: truncated BMP" % path)
+    return np.frombuffer(data, np.uint8, stride * height, off_bits), stride, width, height
+
+
 def write_bmp(path, rgb):
     rgb = np.asarray(rgb, np.uint8)
     _, height, width = rgb.shape

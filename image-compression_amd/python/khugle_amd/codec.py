@@ -60,6 +60,15 @@ class Codec:
         _check(self.L.khg_encode_dev(self._ctx, _ptr(rgb[0]), _ptr(rgb[1]), _ptr(rgb[2]), h, w, lvl,
                                      _ptr(out), out.numel(), _stream()), "encode_dev")
 
+    def encode_bgr_dev(self, pixels, stride, rows, cols, lvl, out):
+        """pixels: the pixel array of a 24-bit BMP as a uint8 cuda tensor (B, G, R per pixel, rows bottom-up, `stride`
+        bytes per row); out as for encode_dev.  The transform kernel reads the file's bytes itself."""
+        assert pixels.is_cuda and pixels.dtype == self.torch.uint8 and pixels.is_contiguous()
+        assert pixels.numel() >= stride * rows
+        assert out.is_cuda and out.dtype == self.torch.uint8 and out.is_contiguous()
+        _check(self.L.khg_encode_bgr_dev(self._ctx, _ptr(pixels), stride, rows, cols, lvl, _ptr(out), out.numel(),
+                                         _stream()), "encode_bgr_dev")
+
     def encode_result(self):
         n = C.c_size_t(0)
         _check(self.L.khg_encode_result(self._ctx, C.byref(n)), "encode_result")

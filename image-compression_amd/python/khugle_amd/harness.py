@@ -8,7 +8,7 @@ import os
 
 import numpy as np
 
-from .bmp import read_bmp, write_bmp
+from .bmp import bmp24_pixels, read_bmp, write_bmp
 from .codec import Codec, peek
 
 PRESETS = {"normal": 0, "high": 1, "extreme": 2}
@@ -46,7 +46,15 @@ def load_bmp_and_compress(path, lvl, codec=None):
     _, h, w = rgb.shape
     c = _codec_for(h, w, codec)
     t = c.torch
-    comp = c.encode(rgb, lvl)
+    raw = bmp24_pixels(path)
+    if raw is not None:  # 24-bit file: its pixel array goes to the GPU as it is (B, G, R, bottom-up)
+        pixels, stride, _, _ = raw
+        d_pix = t.from_numpy(pixels.copy()).cuda(c.device)
+        d_comp = t.zeros(c.comp_bound(h, w), dtype=t.uint8, device=d_pix.device)
+        c.encode_bgr_dev(d_pix, stride, h, w, lvl, d_comp)
+        comp = d_comp[:c.encode_result()].cpu().numpy().tobytes()
+    else:  # palettised: expanded to planar R, G, B on the host
+        comp = c.encode(rgb, lvl)
     decoded = c.decode(comp)  # the application decodes its own result to show it and to measure it
     d_in = t.from_numpy(np.ascontiguousarray(rgb)).cuda(c.device)
     d_out = t.from_numpy(decoded).cuda(c.device)

@@ -73,6 +73,12 @@ int khg_encode(khg_ctx *ctx, const uint8_t *r, const uint8_t *g, const uint8_t *
                uint8_t *out, size_t cap, size_t *out_len);
 int khg_encode_dev(khg_ctx *ctx, const uint8_t *d_r, const uint8_t *d_g, const uint8_t *d_b, int rows, int cols,
                    int lvl, uint8_t *d_out, size_t cap, void *stream);
+/* The same from the pixel array of a 24-bit BMP as it lies in the file: B, G, R bytes per pixel, rows bottom-up,
+ * `stride` bytes per row (3 * cols rounded up to a multiple of 4; stride * rows < 2^32).  Replaces ReadBmp's
+ * conversion loop (KhuGleSignal.cpp:264-272: m_Red[y][x] = pixel[(h - 1 - y) * stride + 3 x + 2], ...) followed by
+ * the u8 -> double copy of Main.cpp:196-204: the kernel that starts the transform reads the file's bytes directly. */
+int khg_encode_bgr_dev(khg_ctx *ctx, const uint8_t *d_pixels, size_t stride, int rows, int cols, int lvl,
+                       uint8_t *d_out, size_t cap, void *stream);
 /* Waits for the context's last encode and returns its status and .comp length. */
 int khg_encode_result(khg_ctx *ctx, size_t *out_len);
 

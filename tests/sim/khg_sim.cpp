@@ -57,12 +57,13 @@ void run_fwd(const KhgFwdArgs& a) {
 }
 
 void forward_all(SimWs& S, const uint8_t* r, const uint8_t* g, const uint8_t* b, int rows, int cols, int lvl,
-                 double* const coef[3], KhgTile tile = KhgTile{0, 1}) {
+                 double* const coef[3], KhgTile tile = KhgTile{0, 1}, int bgr_stride = 0) {
     KhgWorkspace& ws = S.ws;
     memset(ws.hist_cnt, 0, 3 * KHG_NBINS * 4);
     memset(ws.hist_first, 0xFF, 3 * KHG_NBINS * 4);
     memset(ws.res, 0, sizeof(KhgResult));
-    run_fwd<KHG_FWD_RGB>(khg_fwd_args_rgb(ws, r, g, b, rows, cols, lvl, coef, tile));
+    if (bgr_stride) run_fwd<KHG_FWD_BGR>(khg_fwd_args_rgb(ws, r, g, b, rows, cols, lvl, coef, tile, false, bgr_stride));
+    else run_fwd<KHG_FWD_RGB>(khg_fwd_args_rgb(ws, r, g, b, rows, cols, lvl, coef, tile));
     run_fwd<KHG_FWD_PLANES2>(khg_fwd_args_planes(ws, rows, cols, lvl, 2, coef, tile));
 }
 
@@ -84,8 +85,8 @@ int khgsim_forward(const uint8_t* r, const uint8_t* g, const uint8_t* b, int row
 }
 
 static int sim_encode(SimWs& S, const uint8_t* r, const uint8_t* g, const uint8_t* b, int rows, int cols, int lvl,
-                      uint8_t* out, size_t cap, size_t* out_len) {
-    forward_all(S, r, g, b, rows, cols, lvl, nullptr);
+                      uint8_t* out, size_t cap, size_t* out_len, int bgr_stride = 0) {
+    forward_all(S, r, g, b, rows, cols, lvl, nullptr, KhgTile{0, 1}, bgr_stride);
     KhgTableArgs t = khg_table_args(S.ws);
     KhgTableSmem* tsh = new KhgTableSmem;
     for (int p = 0; p < 3; ++p) khg_table_body(t, p, *tsh);
@@ -101,6 +102,14 @@ static int sim_encode(SimWs& S, const uint8_t* r, const uint8_t* g, const uint8_
     delete psh;
     if (out_len) *out_len = (size_t)S.ws.res->total_len;
     return S.ws.res->status;
+}
+
+// the pixel array of a 24-bit BMP (B, G, R per pixel, rows bottom-up, `stride` bytes per row)
+int khgsim_encode_bgr(const uint8_t* pixels, size_t stride, int rows, int cols, int lvl, uint8_t* out, size_t cap,
+                      size_t* out_len) {
+    if (!khg_dims_ok(rows, cols) || lvl < 0 || lvl > 2 || stride < 3 * (size_t)cols) return -1;
+    SimWs S(rows, cols);
+    return sim_encode(S, pixels, nullptr, nullptr, rows, cols, lvl, out, cap, out_len, (int)stride);
 }
 
 int khgsim_encode(const uint8_t* r, const uint8_t* g, const uint8_t* b, int rows, int cols, int lvl,

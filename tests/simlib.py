@@ -29,6 +29,8 @@ def lib():
         L = C.CDLL(SO)
         L.khgsim_encode.argtypes = [_u8p, _u8p, _u8p, C.c_int, C.c_int, C.c_int, _u8p, C.c_size_t,
                                     C.POINTER(C.c_size_t)]
+        L.khgsim_encode_bgr.argtypes = [_u8p, C.c_size_t, C.c_int, C.c_int, C.c_int, _u8p, C.c_size_t,
+                                        C.POINTER(C.c_size_t)]
         L.khgsim_forward.argtypes = [_u8p, _u8p, _u8p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 6
         L.khgsim_decode.argtypes = [_u8p, C.c_size_t, C.c_int, C.c_int, _u8p, _u8p, _u8p, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.POINTER(C.c_int)]
@@ -82,6 +84,26 @@ def encode(rgb, lvl, cap=None):
     out = np.zeros(cap, np.uint8)
     n = C.c_size_t(0)
     rc = lib().khgsim_encode(rgb[0], rgb[1], rgb[2], h, w, lvl, out, cap, C.byref(n))
+    return rc, out[:n.value].tobytes() if rc == 0 else b""
+
+
+def bgr_pixels(rgb):
+    """The pixel array of the 24-bit BMP that holds `rgb` ((3, H, W) u8): B, G, R per pixel, rows bottom-up, rows
+    padded to a multiple of 4 bytes (pad bytes filled with 0xAA: nothing may depend on them)."""
+    _, h, w = rgb.shape
+    stride = (3 * w + 3) // 4 * 4
+    rows = np.full((h, stride), 0xAA, np.uint8)
+    rows[:, :3 * w] = rgb[::-1][:, ::-1].transpose(1, 2, 0).reshape(h, 3 * w)  # channel order B, G, R; bottom-up
+    return rows.reshape(-1), stride
+
+
+def encode_bgr(rgb, lvl):
+    _, h, w = rgb.shape
+    pixels, stride = bgr_pixels(rgb)
+    cap = (36 + h * w * 3 + 3 * 16384 * 8 + 3) // 4 * 4
+    out = np.zeros(cap, np.uint8)
+    n = C.c_size_t(0)
+    rc = lib().khgsim_encode_bgr(pixels, stride, h, w, lvl, out, cap, C.byref(n))
     return rc, out[:n.value].tobytes() if rc == 0 else b""
 
 

@@ -60,6 +60,41 @@ def test_synthetic_stages(codec, shape, lvl):
     assert codec.encode(rgb, lvl) == O.encode(rgb, lvl)
 
 
+@pytest.mark.parametrize("shape", [(8, 8), (24, 40), (264, 520), (1024, 1016), (2160, 3840)])
+def test_bmp_pixel_array_source(codec, shape):
+    """khg_encode_bgr_dev on a 24-bit BMP's pixel array (KhuGleSignal.cpp:264-272 on the GPU) gives the bytes of the
+    planar path and of the oracle."""
+    import torch
+    import oracle_py as O
+    import simlib
+    from khugle_amd import synth_frame
+    rgb = synth_frame(shape[0], shape[1], 5, 1)
+    pixels, stride = simlib.bgr_pixels(rgb)
+    d_pix = torch.from_numpy(pixels).cuda()
+    out = torch.zeros(codec.comp_bound(*shape), dtype=torch.uint8, device="cuda")
+    codec.encode_bgr_dev(d_pix, stride, shape[0], shape[1], 1, out)
+    n = codec.encode_result()
+    got = out[:n].cpu().numpy().tobytes()
+    assert got == codec.encode(rgb, 1)
+    if shape[0] * shape[1] <= 1 << 21:
+        assert got == O.encode(rgb, 1)
+    # geometry the entry point refuses
+    from khugle_amd.lib import ERR_DIMS, KhgError
+    with pytest.raises(KhgError) as e:
+        codec.encode_bgr_dev(d_pix, 3 * shape[1] - 1, shape[0], shape[1], 1, out)
+    assert e.value.code == ERR_DIMS
+
+
+def test_run_bmp_files_through_the_harness(codec, run_images):
+    """load_bmp_and_compress sends a 24-bit file's pixel array to the GPU as it is; palettised files are expanded
+    on the host.  Either way the bytes are the oracle's."""
+    import oracle_py as O
+    from khugle_amd import harness
+    for name in ("cat", "lena"):  # 24-bit, 8-bit palettised
+        rep = harness.load_bmp_and_compress(os.path.join(RUN, name + ".bmp"), 1)
+        assert rep.comp == O.encode(run_images[name], 1)
+
+
 def test_device_synth_matches_host(codec):
     from khugle_amd import synth_frame
     for (h, w, seed, idx) in [(64, 96, 2025, 0), (136, 264, 2025, 5), (256, 256, 1, 1023)]:

@@ -43,6 +43,11 @@ def test_library_exports_every_declared_symbol():
     assert lib.khg_status_string(-2) == b"output buffer too small"
     lib.khg_comp_bound.restype = C.c_size_t
     assert lib.khg_comp_bound(12, 16) == 0 and lib.khg_comp_bound(16, 16) % 4 == 0
+    # 2^31 pixels and more are refused before anything is allocated: raster indices and plane offsets are 32-bit
+    assert lib.khg_comp_bound(32768, 32768) > 0
+    assert lib.khg_comp_bound(65536, 32768) == 0 and lib.khg_comp_bound(46344, 46344) == 0
+    ctx = C.c_void_p(0)
+    assert lib.khg_ctx_create(0, 65536, 65536, C.byref(ctx)) == khg_lib.ERR_ARG and not ctx.value
 
 
 def test_no_cpu_fallback_without_device():

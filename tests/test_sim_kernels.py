@@ -29,6 +29,16 @@ def test_forward_stages_and_bytes(shape, lvl):
     assert rc == 0 and comp == O.encode(rgb, lvl)
 
 
+@pytest.mark.parametrize("shape", [(8, 8), (16, 24), (24, 40), (64, 72), (264, 520), (256, 136)])
+@pytest.mark.parametrize("lvl", [0, 2])
+def test_bmp_pixel_array_source_gives_the_same_bytes(shape, lvl):
+    """The forward kernel reading a 24-bit BMP's pixel array (B, G, R, bottom-up, padded rows:
+    KhuGleSignal.cpp:264-272) against the oracle on the planar picture; widths whose rows need padding included."""
+    rgb = synth_frame(shape[0], shape[1], 5, lvl)
+    rc, comp = S.encode_bgr(rgb, lvl)
+    assert rc == 0 and comp == O.encode(rgb, lvl)
+
+
 @pytest.mark.parametrize("name,lvl", [("cat", 1), ("couple", 0), ("library", 2), ("lena", 1), ("baboon", 0)])
 def test_run_images(run_images, name, lvl):
     rgb = run_images[name]
