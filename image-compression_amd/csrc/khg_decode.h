@@ -25,13 +25,12 @@
 #include "khg_common.h"
 #include "khg_huffman.h"
 
-// Bits per subsequence, a build-time choice (power of two, 128..512).  Measured on 8K frames: 256 shortens one
-// frame's decode (map 290 -> 157 us, write 73 -> 55 us, chain 35 -> 66 us: half as long serial chains per lane in
-// the stretches that need one run per residue class, twice the workgroups to chain) but costs 2 % of batch
-// throughput (twice the first-codeword work and workgroup records); 512 is the better trade for the pipelined
-// batch this library is benchmarked on.
+// Bits per subsequence, a build-time choice (power of two, 128..512).  Measured on 8K frames against 512: 256 halves
+// the serial chains per lane in the stretches that need one run per residue class (map 290 -> 157 us, write 73 ->
+// 55 us for one frame alone) at the price of twice the first-codeword work, workgroup records and chain steps
+// (35 -> 66 us, one lane); in the pipelined batch it decodes 4 % more frames per second.
 #ifndef KHG_SUB_BITS_CFG
-#define KHG_SUB_BITS_CFG 512
+#define KHG_SUB_BITS_CFG 256
 #endif
 
 enum {
