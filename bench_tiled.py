@@ -7,7 +7,8 @@
 Each rank generates its tile of the frame (plus 24 halo rows per side) on its own GPU, so the timed region starts
 with the inputs resident in HBM.  A step = tiled encode (DWT halos recomputed from the halo rows, histogram
 all-reduced over RCCL, chunk bit counts all-reduced, shares of the file reduced to rank 0) followed by tiled decode
-(every rank decodes the stream, reconstructs its rows).  Prints one JSON line on rank 0.
+(every rank entropy-decodes 1/N of each plane's stream, the workgroup records are all-reduced, the decoded symbols go
+point to point to the ranks whose rows need them, every rank reconstructs its rows).  Prints one JSON line on rank 0.
 
 With one process (plain `python bench_tiled.py --side 8192`) it measures the degenerate single-tile case.
 `--virtual N` rehearses N ranks as N contexts on ONE GPU (threads, collectives inside the process): no scaling
@@ -89,7 +90,7 @@ def main():
                 full[:n] = comp
             torch.cuda.synchronize()
             c = time.perf_counter()
-            tile = tiled.decode_tiled(be, full, n, side, side, r, w)
+            tile = tiled.decode_tiled(be, full, n, side, side, r, w, coll=coll)
             torch.cuda.synchronize()
             d = time.perf_counter()
             if it >= args.warmup:

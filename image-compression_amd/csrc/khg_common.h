@@ -14,6 +14,7 @@
 #include <math.h>
 #include <string.h>
 #define KHG_DEV inline
+#define KHG_HOST_DEV inline
 #define KHG_NSLOT(NT) (NT)
 #define KHG_FOR_THREADS(NT) for (int tid = 0; tid < (NT); ++tid)
 #define KHG_SLOT tid
@@ -37,6 +38,7 @@ static inline void khg_atomic_max64(unsigned long long* p, unsigned long long v)
 #else
 #include <hip/hip_runtime.h>
 #define KHG_DEV __device__ __forceinline__
+#define KHG_HOST_DEV __host__ __device__ __forceinline__  // also used by the launch planning on the host
 #define KHG_NSLOT(NT) 1
 #define KHG_FOR_THREADS(NT) for (int tid = (int)threadIdx.x, khg_once_ = 1; khg_once_; khg_once_ = 0)
 #define KHG_SLOT 0

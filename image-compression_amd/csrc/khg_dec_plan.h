@@ -36,6 +36,50 @@ static inline KhgDecArgs khg_dec_args(const KhgWorkspace& ws, const KhgDecWorksp
     return d;
 }
 
+// ---- row-tiled decode with the entropy decode split over the ranks.
+// Active workgroups of each plane's stream, from the first 36 bytes of the file (Reader.h:5-23).  Returns 0 when
+// the header is unusable (the device-side header check then fails the job).
+static inline int khg_tile_active_blocks(const uint8_t hdr36[36], uint32_t nb[3])
+{
+    for (int p = 0; p < 3; ++p) {
+        const uint32_t len = (uint32_t)hdr36[4 * p] | ((uint32_t)hdr36[4 * p + 1] << 8) | ((uint32_t)hdr36[4 * p + 2] << 16) |
+                             ((uint32_t)hdr36[4 * p + 3] << 24);
+        const uint32_t pad = hdr36[32 + p];
+        if (len > 0x7FFFFFFFu || pad > 7 || pad > len) { nb[0] = nb[1] = nb[2] = 0; return 0; }
+        nb[p] = khg_dec_active_blocks(len - pad);
+    }
+    return 1;
+}
+
+// Raster ranges [first, last) of plane `comp`'s symbols that the inverse transform of tile t reads: whole rows,
+// up to four ranges (level 1: packed rows k and hh + k around the tile's band; level 2: the same inside the top
+// left quadrant).  A superset of what the kernels touch (the left halves of the level-1 rows ride along).
+static inline int khg_tile_need_ranges_impl(int rows, int cols, KhgTile t, int comp, uint32_t out[4][2])
+{
+    const int prow = comp ? rows / 2 : rows, pcol = comp ? cols / 2 : cols, hh = prow / 2, hh2 = hh / 2;
+    const int R0 = khg_tile_row0(prow, t), R1 = khg_tile_row1(prow, t);
+    // level 1 reconstructs rows [R0, R1): trips k0 - 2 .. k1 + 2 read packed rows k (reflected into the plane)
+    int a1 = R0 / 2 - 4, b1 = R1 / 2 + 4;
+    if (a1 < 0) a1 = 0;
+    if (b1 > hh) b1 = hh;
+    // level 2 reconstructs rows [rb, re) of the quadrant (khg_inv_plane)
+    int rb = R0 / 2 - 4 < 0 ? 0 : R0 / 2 - 4, re = R1 / 2 + 4 > hh ? hh : R1 / 2 + 4;
+    rb &= ~1;
+    re = (re + 1) & ~1;
+    int a2 = rb / 2 - 4, b2 = re / 2 + 4;
+    if (a2 < 0) a2 = 0;
+    if (b2 > hh2) b2 = hh2;
+    const int rowsets[4][2] = {{a2, b2}, {hh2 + a2, hh2 + b2}, {a1, b1}, {hh + a1, hh + b1}};
+    int n = 0;
+    for (int i = 0; i < 4; ++i) {
+        if (rowsets[i][0] >= rowsets[i][1]) continue;
+        out[n][0] = (uint32_t)rowsets[i][0] * (uint32_t)pcol;
+        out[n][1] = (uint32_t)rowsets[i][1] * (uint32_t)pcol;
+        ++n;
+    }
+    return n;
+}
+
 // Workgroups of the chip that an inverse launch is planned for.
 #ifndef KHG_INV_SLOTS
 #define KHG_INV_SLOTS 1024

@@ -122,7 +122,15 @@ struct KhgDecArgs {
     uint32_t nblocks;
     int16_t* sym[3];
     uint32_t n[3];         // symbols per plane
+    // Row-tiled images: the map and write launches of rank part_rank of part_nranks take the workgroups
+    // [nb * rank / nranks, nb * (rank + 1) / nranks) of each plane's nb active ones (0 ranks = 1: all of them).
+    uint32_t part_rank, part_nranks;
 };
+
+// Active workgroups of plane p's stream.
+KHG_HOST_DEV uint32_t khg_dec_active_blocks(uint32_t nbits) { return (nbits + KHG_BLK_BITS - 1) / KHG_BLK_BITS; }
+// First workgroup of rank r's share of nb workgroups split over n ranks.
+KHG_HOST_DEV uint32_t khg_part_begin(uint32_t nb, uint32_t r, uint32_t n) { return (uint32_t)((uint64_t)nb * r / n); }
 
 static inline void khg_dec_workspace_sizes(int rows, int cols, KhgDecWorkspaceSizes* s)
 {
@@ -351,6 +359,24 @@ KHG_DEV void khg_dec_tree_body(const KhgDecArgs& a, int bid, KhgDecTreeSmem& sh)
             for (uint32_t j = (uint32_t)tid; j < n; j += 256) lut[at + j] = e;
         }
     }
+}
+
+// Which workgroup of the decoder's capacity layout (KhgDecArgs::blk0) block b of a map / write launch works on.
+// Only the workgroups a stream really spans are launched (the host bounds their number by the file length), and
+// they are dispatched Cr, Cb, Y: workgroups run in launch order and the slow ones sit at the start of each plane's
+// stream (the near-fixed-length codes of the LL band need one full run per residue), so this starts every slow
+// workgroup in the first wave of dispatches instead of leaving the chroma ones for last.  ~0u = nothing to do.
+KHG_DEV uint32_t khg_dec_dispatch_order(const KhgDecArgs& a, uint32_t b)
+{
+    if (!a.hdr->ok) return ~0u;
+    const uint32_t n = a.part_nranks ? a.part_nranks : 1u, r = a.part_nranks ? a.part_rank : 0u;
+    for (int p = 2; p >= 0; --p) {
+        const uint32_t nb = khg_dec_active_blocks((uint32_t)a.hdr->nbits[p]);
+        const uint32_t lo = khg_part_begin(nb, r, n), hi = khg_part_begin(nb, r + 1, n);
+        if (b < hi - lo) return a.blk0[p] + lo + b;
+        b -= hi - lo;
+    }
+    return ~0u;
 }
 
 // --------------------------------------------------------------- bit reader

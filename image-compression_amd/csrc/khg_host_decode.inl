@@ -28,6 +28,26 @@ extern "C" int khg_peek(const uint8_t* comp, size_t len, khg_header* hdr)
     return KHG_OK;
 }
 
+// The inverse transform launches of a decode (symbols in the workspace): Decompress.h:274-280, Colorspace.h:25-36.
+static void khg_enqueue_inverse(khg_ctx* c, int rows, int cols, uint8_t* d_r, uint8_t* d_g, uint8_t* d_b, hipStream_t st,
+                                KhgTile tile, double* const ycbcr[3])
+{
+    {  // Decompress.h:274-276: level 2 of the three components, one launch
+        const KhgInvArgs a = khg_inv_args(c->ws, c->dws, rows, cols, 0, 3, 2, tile);
+        hipLaunchKernelGGL((khg_inv_kernel<KHG_INV_PLANES2>), dim3(a.nwg), dim3(256), 0, st, a);
+    }
+    if (ycbcr) {  // Decompress.h:278-280 into the caller's f64 planes
+        const KhgInvArgs a = khg_inv_args(c->ws, c->dws, rows, cols, 0, 3, 1, tile, ycbcr);
+        hipLaunchKernelGGL((khg_inv_kernel<KHG_INV_PLANES1>), dim3(a.nwg), dim3(256), 0, st, a);
+    } else {  // Cb and Cr first; the luma launch also does Colorspace.h:25-36 + Main.cpp:307-315
+        const KhgInvArgs ac = khg_inv_args(c->ws, c->dws, rows, cols, 1, 2, 1, tile);
+        hipLaunchKernelGGL((khg_inv_kernel<KHG_INV_PLANES1>), dim3(ac.nwg), dim3(256), 0, st, ac);
+        KhgInvArgs ay = khg_inv_args(c->ws, c->dws, rows, cols, 0, 1, 1, tile);
+        ay.r = d_r; ay.g = d_g; ay.b = d_b;
+        hipLaunchKernelGGL((khg_inv_kernel<KHG_INV_RGB>), dim3(ay.nwg), dim3(256), 0, st, ay);
+    }
+}
+
 // ycbcr != null: stop before the colour conversion and leave the f64 planes there (DecompressImage's outputs).
 static int khg_decode_enqueue(khg_ctx* c, const uint8_t* d_comp, size_t len, int rows, int cols, uint8_t* d_r,
                               uint8_t* d_g, uint8_t* d_b, void* stream, KhgTile tile, double* const ycbcr[3] = nullptr)
@@ -52,20 +72,7 @@ static int khg_decode_enqueue(khg_ctx* c, const uint8_t* d_comp, size_t len, int
     hipLaunchKernelGGL((khg_dec_map_kernel<KHG_MAXOFF>), dim3(grid_dec), dim3(256), 0, st, d);
     hipLaunchKernelGGL(khg_dec_chain_kernel, dim3(3), dim3(256), 0, st, d);
     hipLaunchKernelGGL(khg_dec_write_kernel, dim3(grid_dec), dim3(256), 0, st, d);
-    {  // Decompress.h:274-276: level 2 of the three components, one launch
-        const KhgInvArgs a = khg_inv_args(c->ws, c->dws, rows, cols, 0, 3, 2, tile);
-        hipLaunchKernelGGL((khg_inv_kernel<KHG_INV_PLANES2>), dim3(a.nwg), dim3(256), 0, st, a);
-    }
-    if (ycbcr) {  // Decompress.h:278-280 into the caller's f64 planes
-        const KhgInvArgs a = khg_inv_args(c->ws, c->dws, rows, cols, 0, 3, 1, tile, ycbcr);
-        hipLaunchKernelGGL((khg_inv_kernel<KHG_INV_PLANES1>), dim3(a.nwg), dim3(256), 0, st, a);
-    } else {  // Cb and Cr first; the luma launch also does Colorspace.h:25-36 + Main.cpp:307-315
-        const KhgInvArgs ac = khg_inv_args(c->ws, c->dws, rows, cols, 1, 2, 1, tile);
-        hipLaunchKernelGGL((khg_inv_kernel<KHG_INV_PLANES1>), dim3(ac.nwg), dim3(256), 0, st, ac);
-        KhgInvArgs ay = khg_inv_args(c->ws, c->dws, rows, cols, 0, 1, 1, tile);
-        ay.r = d_r; ay.g = d_g; ay.b = d_b;
-        hipLaunchKernelGGL((khg_inv_kernel<KHG_INV_RGB>), dim3(ay.nwg), dim3(256), 0, st, ay);
-    }
+    khg_enqueue_inverse(c, rows, cols, d_r, d_g, d_b, st, tile, ycbcr);
     KHG_HIP(hipGetLastError());
     KHG_HIP(hipMemcpyAsync(c->h_res, c->ws.res, sizeof(KhgResult), hipMemcpyDeviceToHost, st));
     return khg_end(c, st, 2);

@@ -140,3 +140,192 @@ extern "C" int khg_tile_decode_dev(khg_ctx* c, const uint8_t* d_comp, size_t len
     const KhgTile t = {rank, nranks};
     return khg_decode_enqueue(c, d_comp, len, rows, cols, d_r, d_g, d_b, stream, t);
 }
+
+// ---- tiled decode with the entropy decode split over the ranks.  Every rank holds the whole file; rank t maps and
+// decodes the workgroup spans [nb * t / n, nb * (t + 1) / n) of each plane's stream.  Between the steps the caller
+//   1. sums the workgroup records over the ranks (khg_tile_blk_get / all-reduce SUM / khg_tile_blk_set: the
+//      records of other ranks' spans are zero here), so that every rank can chain all spans from bit 0;
+//   2. moves decoded symbols from the ranks that hold them to the ranks whose rows need them
+//      (khg_tile_sym_get / point-to-point / khg_tile_sym_set, ranges from khg_tile_decode_write_dev and
+//      khg_tile_need_ranges).
+
+static KhgDecArgs khg_tdec_args(khg_ctx* c)
+{
+    KhgDecArgs d = khg_dec_args(c->ws, c->dws, c->tdec_comp, c->tdec_len, c->tile_rows, c->tile_cols);
+    d.part_rank = (uint32_t)c->tile.rank;
+    d.part_nranks = (uint32_t)c->tile.nranks;
+    return d;
+}
+
+static unsigned khg_tdec_grid(const khg_ctx* c)
+{
+    unsigned g = 0;
+    for (int p = 0; p < 3; ++p)
+        g += khg_part_begin(c->tdec_nb[p], (uint32_t)c->tile.rank + 1, (uint32_t)c->tile.nranks) -
+             khg_part_begin(c->tdec_nb[p], (uint32_t)c->tile.rank, (uint32_t)c->tile.nranks);
+    return g;
+}
+
+extern "C" int khg_tile_decode_map_dev(khg_ctx* c, const uint8_t* d_comp, size_t len, int rows, int cols, int rank,
+                                       int nranks, void* stream)
+{
+    int rc = khg_tile_check(c, rows, cols, 0, rank, nranks);
+    if (rc) return rc;
+    if (!d_comp || ((uintptr_t)d_comp & 3)) return KHG_ERR_ARG;
+    if (len < 36 + 24) return KHG_ERR_FORMAT;
+    hipStream_t st = (hipStream_t)stream;
+    KHG_HIP(hipSetDevice(c->device));
+    if ((rc = khg_begin(c, st))) return rc;
+    uint8_t hdr36[36];  // the host needs the stream lengths to size the launches and the exchange
+    KHG_HIP(hipMemcpyAsync(hdr36, d_comp, 36, hipMemcpyDeviceToHost, st));
+    KHG_HIP(hipStreamSynchronize(st));
+    c->tile = KhgTile{rank, nranks};
+    c->tile_rows = rows; c->tile_cols = cols;
+    c->tdec_comp = d_comp; c->tdec_len = len;
+    khg_tile_active_blocks(hdr36, c->tdec_nb);
+    const KhgDecArgs d = khg_tdec_args(c);
+    for (int p = 0; p < 3; ++p) {  // a stream can span no more workgroups than the workspace holds
+        const uint32_t cap = (p < 2 ? d.blk0[p + 1] : d.nblocks) - d.blk0[p];
+        if (c->tdec_nb[p] > cap) c->tdec_nb[p] = cap;  // the device-side header check fails such a file
+    }
+    KHG_HIP(hipMemsetAsync(c->ws.res, 0, sizeof(KhgResult), st));
+    for (int p = 0; p < 3; ++p)
+        if (c->tdec_nb[p])
+            KHG_HIP(hipMemsetAsync(c->dws.blk + d.blk0[p], 0, (size_t)c->tdec_nb[p] * sizeof(KhgBlkInfo), st));
+    hipLaunchKernelGGL(khg_dec_header_kernel, dim3(1), dim3(256), 0, st, d);
+    hipLaunchKernelGGL(khg_dec_tree_kernel, dim3(3), dim3(256), 0, st, d);
+    const unsigned grid = khg_tdec_grid(c);
+    if (grid) {
+        hipLaunchKernelGGL((khg_dec_map_kernel<KHG_MAP_SMALL>), dim3(grid), dim3(256), 0, st, d);
+        hipLaunchKernelGGL((khg_dec_map_kernel<KHG_MAXOFF>), dim3(grid), dim3(256), 0, st, d);
+    }
+    KHG_HIP(hipGetLastError());
+    c->tdec_step = 1;
+    return khg_end(c, st, 0);
+}
+
+// 32-bit words of the workgroup records of all three planes (what khg_tile_blk_get / _set move).
+extern "C" size_t khg_tile_blk_words(khg_ctx* c)
+{
+    if (!c || c->tdec_step < 1) return 0;
+    return ((size_t)c->tdec_nb[0] + c->tdec_nb[1] + c->tdec_nb[2]) * (sizeof(KhgBlkInfo) / 4);
+}
+
+static int khg_tile_blk_copy(khg_ctx* c, uint32_t* d_words, void* stream, bool get)
+{
+    if (!c || !d_words || c->tdec_step < 1) return KHG_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    KHG_HIP(hipSetDevice(c->device));
+    int rc = khg_begin(c, st);
+    if (rc) return rc;
+    const KhgDecArgs d = khg_tdec_args(c);
+    size_t at = 0;
+    for (int p = 0; p < 3; ++p) {
+        const size_t bytes = (size_t)c->tdec_nb[p] * sizeof(KhgBlkInfo);
+        if (!bytes) continue;
+        void* rec = c->dws.blk + d.blk0[p];
+        KHG_HIP(hipMemcpyAsync(get ? (void*)(d_words + at) : rec, get ? rec : (void*)(d_words + at), bytes,
+                               hipMemcpyDeviceToDevice, st));
+        at += bytes / 4;
+    }
+    return khg_end(c, st, 0);
+}
+
+extern "C" int khg_tile_blk_get(khg_ctx* c, uint32_t* d_words, void* stream) { return khg_tile_blk_copy(c, d_words, stream, true); }
+extern "C" int khg_tile_blk_set(khg_ctx* c, const uint32_t* d_words, void* stream)
+{
+    return khg_tile_blk_copy(c, (uint32_t*)d_words, stream, false);
+}
+
+// Chains all spans (every rank, from the summed records), decodes this rank's spans into its symbol planes and
+// reports where each rank's symbols start: bounds[p * (nranks + 1) + t] = raster index of the first symbol rank t
+// decodes in plane p, bounds[p * (nranks + 1) + nranks] = symbols decoded in the plane (the cells behind them are
+// zero on every rank, Huffman.h:35).  Waits for the stream.
+extern "C" int khg_tile_decode_write_dev(khg_ctx* c, uint32_t* bounds, void* stream)
+{
+    if (!c || !bounds || c->tdec_step != 1) return KHG_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    KHG_HIP(hipSetDevice(c->device));
+    int rc = khg_begin(c, st);
+    if (rc) return rc;
+    const KhgDecArgs d = khg_tdec_args(c);
+    const int n = c->tile.nranks;
+    hipLaunchKernelGGL(khg_dec_chain_kernel, dim3(3), dim3(256), 0, st, d);
+    const unsigned grid = khg_tdec_grid(c);
+    if (grid) hipLaunchKernelGGL(khg_dec_write_kernel, dim3(grid), dim3(256), 0, st, d);
+    KHG_HIP(hipGetLastError());
+    KHG_HIP(hipMemcpyAsync(c->h_res, c->ws.res, sizeof(KhgResult), hipMemcpyDeviceToHost, st));
+    for (int p = 0; p < 3; ++p)
+        for (int t = 0; t < n; ++t) {
+            const uint32_t b = khg_part_begin(c->tdec_nb[p], (uint32_t)t, (uint32_t)n);
+            uint32_t* dst = &bounds[p * (n + 1) + t];
+            if (b < c->tdec_nb[p]) KHG_HIP(hipMemcpyAsync(dst, &c->dws.blk[d.blk0[p] + b].out, 4, hipMemcpyDeviceToHost, st));
+            else *dst = 0xFFFFFFFFu;  // no span: patched below
+        }
+    KHG_HIP(hipStreamSynchronize(st));
+    for (int p = 0; p < 3; ++p) {
+        uint32_t total = (uint32_t)c->h_res->bits[p];  // symbols decoded (khg_dec_chain_body)
+        if (total > d.n[p]) total = d.n[p];
+        bounds[p * (n + 1) + n] = total;
+        for (int t = n - 1; t >= 0; --t) {  // ranks without a span own nothing; starts never pass the total
+            uint32_t& v = bounds[p * (n + 1) + t];
+            if (v > bounds[p * (n + 1) + t + 1]) v = bounds[p * (n + 1) + t + 1];
+        }
+    }
+    c->tdec_step = 2;
+    return khg_end(c, st, 0);
+}
+
+extern "C" int khg_tile_need_ranges(int rows, int cols, int rank, int nranks, int plane, uint32_t* ranges)
+{
+    KhgTile t = {rank, nranks};
+    if (!ranges || plane < 0 || plane > 2 || !khg_dims_ok(rows, cols) || !khg_tile_ok(rows, t)) return KHG_ERR_DIMS;
+    uint32_t r[4][2];
+    const int n = khg_tile_need_ranges_impl(rows, cols, t, plane, r);
+    for (int i = 0; i < n; ++i) {
+        ranges[2 * i] = r[i][0];
+        ranges[2 * i + 1] = r[i][1];
+    }
+    return n;
+}
+
+static int khg_tile_sym_copy(khg_ctx* c, int plane, uint32_t first, uint32_t count, int16_t* d_buf, void* stream, bool get)
+{
+    if (!c || !d_buf || plane < 0 || plane > 2 || c->tdec_step != 2) return KHG_ERR_ARG;
+    const uint64_t n = (uint64_t)c->tile_rows * c->tile_cols / (plane ? 4 : 1);
+    if ((uint64_t)first + count > n) return KHG_ERR_ARG;
+    if (!count) return KHG_OK;
+    hipStream_t st = (hipStream_t)stream;
+    KHG_HIP(hipSetDevice(c->device));
+    int rc = khg_begin(c, st);
+    if (rc) return rc;
+    int16_t* sym = c->ws.sym[plane] + first;
+    KHG_HIP(hipMemcpyAsync(get ? d_buf : sym, get ? sym : d_buf, (size_t)count * 2, hipMemcpyDeviceToDevice, st));
+    return khg_end(c, st, 0);
+}
+
+extern "C" int khg_tile_sym_get(khg_ctx* c, int plane, uint32_t first, uint32_t count, int16_t* d_dst, void* stream)
+{
+    return khg_tile_sym_copy(c, plane, first, count, d_dst, stream, true);
+}
+extern "C" int khg_tile_sym_set(khg_ctx* c, int plane, uint32_t first, uint32_t count, const int16_t* d_src, void* stream)
+{
+    return khg_tile_sym_copy(c, plane, first, count, (int16_t*)d_src, stream, false);
+}
+
+// The inverse transform and colour conversion of this rank's rows from the symbols now in place; result and status
+// as after khg_tile_decode_dev (khg_last_status).
+extern "C" int khg_tile_decode_inverse_dev(khg_ctx* c, uint8_t* d_r, uint8_t* d_g, uint8_t* d_b, void* stream)
+{
+    if (!c || c->tdec_step != 2) return KHG_ERR_ARG;
+    if (!d_r || !d_g || !d_b || ((uintptr_t)d_r & 7) || ((uintptr_t)d_g & 7) || ((uintptr_t)d_b & 7)) return KHG_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    KHG_HIP(hipSetDevice(c->device));
+    int rc = khg_begin(c, st);
+    if (rc) return rc;
+    khg_enqueue_inverse(c, c->tile_rows, c->tile_cols, d_r, d_g, d_b, st, c->tile, nullptr);
+    KHG_HIP(hipGetLastError());
+    KHG_HIP(hipMemcpyAsync(c->h_res, c->ws.res, sizeof(KhgResult), hipMemcpyDeviceToHost, st));
+    c->tdec_step = 0;
+    return khg_end(c, st, 2);
+}

@@ -70,22 +70,6 @@ __global__ __launch_bounds__(256) void khg_dec_tree_kernel(KhgDecArgs a)
     khg_dec_tree_body(a, (int)blockIdx.x, sh);
 }
 
-// Which workgroup of the decoder's capacity layout (KhgDecArgs::blk0) block b of a launch works on.  Only the
-// workgroups a stream really spans are launched (the host bounds their number by the file length), and they are
-// dispatched Cr, Cb, Y: workgroups run in blockIdx order and the slow ones sit at the start of each plane's stream
-// (the near-fixed-length codes of the LL band need one full run per residue), so this starts every slow
-// workgroup in the first wave of dispatches instead of leaving the chroma ones for last.  ~0u = nothing to do.
-__device__ __forceinline__ uint32_t khg_dec_dispatch_order(const KhgDecArgs& a, uint32_t b)
-{
-    if (!a.hdr->ok) return ~0u;
-    for (int p = 2; p >= 0; --p) {
-        const uint32_t nb = ((uint32_t)a.hdr->nbits[p] + KHG_BLK_BITS - 1) / KHG_BLK_BITS;
-        if (b < nb) return a.blk0[p] + b;
-        b -= nb;
-    }
-    return ~0u;
-}
-
 // MO = KHG_MAP_SMALL: planes whose longest code has at most 32 bits (three workgroups per CU);
 // MO = KHG_MAXOFF: the others.  Both are launched; a workgroup of the wrong one returns at once.
 template <int MO>
@@ -175,6 +159,11 @@ struct khg_ctx {
     // tiled encode in progress (khg_tile_*)
     KhgTile tile;
     int tile_rows, tile_cols, tile_lvl;
+    // tiled decode in progress (khg_tile_decode_map_dev .. khg_tile_decode_inverse_dev)
+    const uint8_t* tdec_comp;
+    size_t tdec_len;
+    uint32_t tdec_nb[3];  // active workgroups of each plane's stream
+    int tdec_step;        // 0 none, 1 mapped, 2 written
 };
 
 static size_t khg_align(size_t v) { return (v + 255) & ~(size_t)255; }

@@ -65,6 +65,15 @@ SYMBOLS = [
     ("khg_tile_bits_set", C.c_int, [_P, _P, _P]),
     ("khg_tile_pack_dev", C.c_int, [_P, _P, C.c_size_t, _P]),
     ("khg_tile_decode_dev", C.c_int, [_P, _P, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P]),
+    ("khg_tile_decode_map_dev", C.c_int, [_P, _P, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    ("khg_tile_blk_words", C.c_size_t, [_P]),
+    ("khg_tile_blk_get", C.c_int, [_P, _P, _P]),
+    ("khg_tile_blk_set", C.c_int, [_P, _P, _P]),
+    ("khg_tile_decode_write_dev", C.c_int, [_P, _P, _P]),
+    ("khg_tile_need_ranges", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    ("khg_tile_sym_get", C.c_int, [_P, C.c_int, C.c_uint32, C.c_uint32, _P, _P]),
+    ("khg_tile_sym_set", C.c_int, [_P, C.c_int, C.c_uint32, C.c_uint32, _P, _P]),
+    ("khg_tile_decode_inverse_dev", C.c_int, [_P, _P, _P, _P, _P]),
     ("khg_profile_luma_forward", C.c_int, [_P, C.c_int]),
     ("khg_profile_read", C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     ("khg_ssim_dev", C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.POINTER(C.c_double), _P]),

@@ -7,6 +7,9 @@ Rank t of n owns image rows [rows*t/n, rows*(t+1)/n).  Data movement between ran
                      -> every rank builds the same table, tree and codes
   * chunk bits     : all-reduce SUM -> every rank knows the bit offset of every chunk
   * file bytes     : reduce SUM of the ranks' disjoint shares to the rank that keeps the file
+  * decode         : the entropy decode is split over the ranks (each decodes 1/n of every plane's stream):
+                     all-reduce SUM of the workgroup records -> every rank chains all spans; then decoded symbols
+                     go point to point from the ranks that hold them to the ranks whose rows need them
 On GPUs the process group is RCCL (backend "nccl"); the CPU tests run the same code over gloo with the kernel
 simulator behind the same backend interface.
 """
@@ -115,6 +118,55 @@ class HipTileBackend:
             raise _lib.KhgError(st, "tile_decode")
         return out
 
+    # ---- decode with the entropy decode split over the ranks
+    def dec_map(self, comp, length, rows, cols, rank, world):
+        self.shape = (rows, cols, world)
+        self.rank = rank
+        _check(self.L.khg_tile_decode_map_dev(self.c._ctx, _ptr(comp), length, rows, cols, rank, world, _stream()),
+               "tile_decode_map")
+
+    def blk_get(self):
+        words = torch.empty(self.L.khg_tile_blk_words(self.c._ctx), dtype=torch.int32, device=self.dev)
+        if words.numel():
+            _check(self.L.khg_tile_blk_get(self.c._ctx, _ptr(words), _stream()), "tile_blk_get")
+        return words
+
+    def blk_set(self, words):
+        if words.numel():
+            _check(self.L.khg_tile_blk_set(self.c._ctx, _ptr(words), _stream()), "tile_blk_set")
+
+    def dec_write(self):
+        world = self.shape[2]
+        bounds = (C.c_uint32 * (3 * (world + 1)))()
+        _check(self.L.khg_tile_decode_write_dev(self.c._ctx, bounds, _stream()), "tile_decode_write")
+        return list(bounds)
+
+    def need_ranges(self, rows, cols, rank, world, plane):
+        r = (C.c_uint32 * 8)()
+        n = self.L.khg_tile_need_ranges(rows, cols, rank, world, plane, r)
+        if n < 0:
+            raise _lib.KhgError(n, "tile_need_ranges")
+        return [(r[2 * i], r[2 * i + 1]) for i in range(n)]
+
+    def sym_get(self, plane, first, count):
+        t = torch.empty(count, dtype=torch.int16, device=self.dev)
+        _check(self.L.khg_tile_sym_get(self.c._ctx, plane, first, count, _ptr(t), _stream()), "tile_sym_get")
+        return t
+
+    def sym_set(self, plane, first, t):
+        _check(self.L.khg_tile_sym_set(self.c._ctx, plane, first, t.numel(), _ptr(t), _stream()), "tile_sym_set")
+
+    def sym_buffer(self, count):
+        return torch.empty(count, dtype=torch.int16, device=self.dev)
+
+    def dec_inverse(self):
+        rows, cols, world = self.shape
+        r0, r1 = tile_rows(rows, self.rank, world)
+        out = torch.empty((3, r1 - r0, cols), dtype=torch.uint8, device=self.dev)
+        _check(self.L.khg_tile_decode_inverse_dev(self.c._ctx, _ptr(out[0]), _ptr(out[1]), _ptr(out[2]), _stream()),
+               "tile_decode_inverse")
+        return out, self.c.last_status_after_decode()
+
 
 class DistCollectives:
     """The three collectives over a torch.distributed process group (RCCL on GPUs, gloo on CPUs)."""
@@ -134,6 +186,17 @@ class DistCollectives:
     def reduce_sum(self, t, dst):
         if self.on:
             dist.reduce(t, dst=dst, op=dist.ReduceOp.SUM, group=self.group)
+
+    def exchange(self, sends, recvs):
+        """sends: [(dst rank, tensor)], recvs: [(src rank, tensor)]; between any two ranks the tensors are matched in
+        list order."""
+        if not self.on:
+            return
+        ops = [dist.P2POp(dist.isend, t, dst, self.group) for dst, t in sends]
+        ops += [dist.P2POp(dist.irecv, t, src, self.group) for src, t in recvs]
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
 
 
 def encode_tiled(backend, strip, rows, cols, lvl, rank, world, coll=None, dst=0):
@@ -169,6 +232,55 @@ def encode_tiled(backend, strip, rows, cols, lvl, rank, world, coll=None, dst=0)
     return words.view(torch.uint8)[:total]
 
 
-def decode_tiled(backend, comp, length, rows, cols, rank, world):
-    """comp: the whole file on every rank.  Returns the rank's rows of the picture, (3, rows/world, cols) uint8."""
-    return backend.decode(comp, length, rows, cols, rank, world)
+def symbol_pieces(bounds, need, world):
+    """Who sends what to whom after the split entropy decode.  bounds[p][t] = raster index of the first symbol of
+    plane p that rank t holds (bounds[p][world] = symbols decoded); need[t][p] = raster ranges rank t's inverse
+    transform reads.  Returns [(src, dst, plane, first, count)] in the one order every rank uses."""
+    out = []
+    for dst in range(world):
+        for p in range(3):
+            for a, b in need[dst][p]:
+                for src in range(world):
+                    if src == dst:
+                        continue
+                    lo, hi = max(a, bounds[p][src]), min(b, bounds[p][src + 1])
+                    if lo < hi:
+                        out.append((src, dst, p, lo, hi - lo))
+    return out
+
+
+def decode_tiled(backend, comp, length, rows, cols, rank, world, coll=None, split=None):
+    """comp: the whole file on every rank.  Returns the rank's rows of the picture, (3, rows/world, cols) uint8.
+    split (default: world > 1): every rank entropy-decodes 1/world of each plane's stream and the symbols are
+    exchanged; otherwise every rank decodes the whole stream."""
+    if split is None:
+        split = world > 1
+    if not split:
+        return backend.decode(comp, length, rows, cols, rank, world)
+    coll = coll or DistCollectives()
+    backend.dec_map(comp, length, rows, cols, rank, world)
+    words = backend.blk_get()
+    coll.all_reduce_sum(words)  # other ranks' records are zero here: the sum is the union
+    backend.blk_set(words)
+    flat = backend.dec_write()  # identical on every rank (the chain runs on the summed records)
+    bounds = [flat[p * (world + 1):(p + 1) * (world + 1)] for p in range(3)]
+    need = [[backend.need_ranges(rows, cols, t, world, p) for p in range(3)] for t in range(world)]
+    sends, recvs, landing = [], [], []
+    for src, dst, p, first, count in symbol_pieces(bounds, need, world):
+        if src == rank:
+            sends.append((dst, backend.sym_get(p, first, count)))
+        elif dst == rank:
+            buf = backend.sym_buffer(count)
+            recvs.append((src, buf))
+            landing.append((p, first, buf))
+    coll.exchange(sends, recvs)
+    for p, first, buf in landing:
+        backend.sym_set(p, first, buf)
+    out, status = backend.dec_inverse()
+    # a damaged stream may show on the rank that decoded that part only: agree before anyone raises
+    st = torch.tensor([status], dtype=torch.int32, device=out.device)
+    coll.all_reduce_min(st)
+    worst = int(st.item())
+    if worst != 0:
+        raise _lib.KhgError(worst, "decode_tiled (rank %d saw status %d)" % (rank, status))
+    return out

@@ -186,6 +186,31 @@ int khg_tile_pack_dev(khg_ctx *ctx, uint8_t *d_out, size_t cap, void *stream);
 int khg_tile_decode_dev(khg_ctx *ctx, const uint8_t *d_comp, size_t len, int rows, int cols, int rank, int nranks,
                         uint8_t *d_r, uint8_t *d_g, uint8_t *d_b, void *stream);
 
+/* Tiled decode with the entropy decode (Huffman.h:33-55) split over the ranks instead of repeated on each: every
+ * rank holds the whole file and decodes the spans [nb*t/n, nb*(t+1)/n) of each plane's stream.
+ *   1. khg_tile_decode_map_dev    header, trees, and the start-offset maps of this rank's spans
+ *   2. khg_tile_blk_get  ->  all-reduce SUM over khg_tile_blk_words 32-bit words (other ranks' records are zero)
+ *                             ->  khg_tile_blk_set: every rank can now chain all spans from bit 0
+ *   3. khg_tile_decode_write_dev  chains all spans, decodes this rank's spans into its symbol planes; returns (host
+ *                             memory, after waiting for the stream) bounds[p*(n+1)+t] = raster index of the first
+ *                             symbol of plane p that rank t holds, bounds[p*(n+1)+n] = symbols decoded in plane p
+ *   4. point to point: each rank sends the parts of its symbols that lie in another rank's
+ *                             khg_tile_need_ranges (raster ranges [first, last) of whole symbol rows, at most 4
+ *                             per plane; returns their number) -- khg_tile_sym_get on the sender, khg_tile_sym_set
+ *                             on the receiver
+ *   5. khg_tile_decode_inverse_dev  dequantiser, inverse DWT, colour conversion of the tile's rows
+ *                             (Decompress.h:56-126, 274-280); khg_last_status: the job's status. */
+int khg_tile_decode_map_dev(khg_ctx *ctx, const uint8_t *d_comp, size_t len, int rows, int cols, int rank, int nranks,
+                            void *stream);
+size_t khg_tile_blk_words(khg_ctx *ctx);
+int khg_tile_blk_get(khg_ctx *ctx, uint32_t *d_words, void *stream);
+int khg_tile_blk_set(khg_ctx *ctx, const uint32_t *d_words, void *stream);
+int khg_tile_decode_write_dev(khg_ctx *ctx, uint32_t *bounds, void *stream);
+int khg_tile_need_ranges(int rows, int cols, int rank, int nranks, int plane, uint32_t *ranges);
+int khg_tile_sym_get(khg_ctx *ctx, int plane, uint32_t first, uint32_t count, int16_t *d_dst, void *stream);
+int khg_tile_sym_set(khg_ctx *ctx, int plane, uint32_t first, uint32_t count, const int16_t *d_src, void *stream);
+int khg_tile_decode_inverse_dev(khg_ctx *ctx, uint8_t *d_r, uint8_t *d_g, uint8_t *d_b, void *stream);
+
 /* Measurement aid: while enabled, khg_encode_dev brackets its luma level-1 forward launch with HIP events on
  * the caller's stream, and the kernel notes the device clock at which its first workgroup starts and its last
  * one ends; khg_encode_result adds both durations to per-context tallies that khg_profile_read returns

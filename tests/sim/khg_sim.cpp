@@ -120,6 +120,26 @@ int khgsim_encode(const uint8_t* r, const uint8_t* g, const uint8_t* b, int rows
 }
 
 // Mirrors khg_decode_dev / khg_tile_decode_dev (r, g, b receive the tile's rows only) / khg_decode_ycbcr_dev.
+static void sim_inverse(SimWs& S, int rows, int cols, uint8_t* r, uint8_t* g, uint8_t* b, KhgTile tile,
+                        double* const ycbcr[3]) {
+    KhgInvSmemAny* ish = new KhgInvSmemAny;
+    {
+        const KhgInvArgs a = khg_inv_args(S.ws, S.dws, rows, cols, 0, 3, 2, tile);
+        for (int wg = 0; wg < a.nwg; ++wg) khg_inv_launch_body<KHG_INV_PLANES2>(a, wg, *ish);
+    }
+    if (ycbcr) {
+        const KhgInvArgs a = khg_inv_args(S.ws, S.dws, rows, cols, 0, 3, 1, tile, ycbcr);
+        for (int wg = 0; wg < a.nwg; ++wg) khg_inv_launch_body<KHG_INV_PLANES1>(a, wg, *ish);
+    } else {
+        const KhgInvArgs ac = khg_inv_args(S.ws, S.dws, rows, cols, 1, 2, 1, tile);
+        for (int wg = 0; wg < ac.nwg; ++wg) khg_inv_launch_body<KHG_INV_PLANES1>(ac, wg, *ish);
+        KhgInvArgs ay = khg_inv_args(S.ws, S.dws, rows, cols, 0, 1, 1, tile);
+        ay.r = r; ay.g = g; ay.b = b;
+        for (int wg = 0; wg < ay.nwg; ++wg) khg_inv_launch_body<KHG_INV_RGB>(ay, wg, *ish);
+    }
+    delete ish;
+}
+
 static int sim_decode(SimWs& S, const uint8_t* comp, size_t len, int rows, int cols, uint8_t* r, uint8_t* g, uint8_t* b,
                       int16_t* qy, int16_t* qcb, int16_t* qcr, int* passes_used, KhgTile tile,
                       double* const ycbcr[3] = nullptr) {
@@ -144,22 +164,7 @@ static int sim_decode(SimWs& S, const uint8_t* comp, size_t len, int rows, int c
     delete lsh2;
     delete wsh;
     delete ssh;
-    KhgInvSmemAny* ish = new KhgInvSmemAny;
-    {
-        const KhgInvArgs a = khg_inv_args(S.ws, S.dws, rows, cols, 0, 3, 2, tile);
-        for (int wg = 0; wg < a.nwg; ++wg) khg_inv_launch_body<KHG_INV_PLANES2>(a, wg, *ish);
-    }
-    if (ycbcr) {
-        const KhgInvArgs a = khg_inv_args(S.ws, S.dws, rows, cols, 0, 3, 1, tile, ycbcr);
-        for (int wg = 0; wg < a.nwg; ++wg) khg_inv_launch_body<KHG_INV_PLANES1>(a, wg, *ish);
-    } else {
-        const KhgInvArgs ac = khg_inv_args(S.ws, S.dws, rows, cols, 1, 2, 1, tile);
-        for (int wg = 0; wg < ac.nwg; ++wg) khg_inv_launch_body<KHG_INV_PLANES1>(ac, wg, *ish);
-        KhgInvArgs ay = khg_inv_args(S.ws, S.dws, rows, cols, 0, 1, 1, tile);
-        ay.r = r; ay.g = g; ay.b = b;
-        for (int wg = 0; wg < ay.nwg; ++wg) khg_inv_launch_body<KHG_INV_RGB>(ay, wg, *ish);
-    }
-    delete ish;
+    sim_inverse(S, rows, cols, r, g, b, tile, ycbcr);
     size_t ny = (size_t)rows * cols;
     if (qy) memcpy(qy, S.ws.sym[0], ny * 2);
     if (qcb) memcpy(qcb, S.ws.sym[1], ny / 4 * 2);
@@ -241,7 +246,23 @@ struct SimTile {
     SimWs S;
     KhgTile t;
     int rows, cols, lvl;
+    // partitioned decode in progress
+    std::vector<uint8_t> comp;
+    size_t comp_len = 0;
+    uint32_t nb[3] = {0, 0, 0};
     SimTile(int r, int c) : S(r, c), t{0, 1}, rows(r), cols(c), lvl(0) {}
+    KhgDecArgs dec_args() {
+        KhgDecArgs d = khg_dec_args(S.ws, S.dws, comp.data(), comp_len, rows, cols);
+        d.part_rank = (uint32_t)t.rank;
+        d.part_nranks = (uint32_t)t.nranks;
+        return d;
+    }
+    uint32_t grid() const {
+        uint32_t g = 0;
+        for (int p = 0; p < 3; ++p)
+            g += khg_part_begin(nb[p], (uint32_t)t.rank + 1, (uint32_t)t.nranks) - khg_part_begin(nb[p], (uint32_t)t.rank, (uint32_t)t.nranks);
+        return g;
+    }
 };
 
 void* khgsim_tile_create(int rows, int cols) { return khg_dims_ok(rows, cols) ? new SimTile(rows, cols) : nullptr; }
@@ -318,6 +339,113 @@ int khgsim_tile_decode(void* h, const uint8_t* comp, size_t len, int rows, int c
     KhgTile t = {rank, nranks};
     if (!khg_tile_ok(rows, t) || rows != T->rows || cols != T->cols) return -1;
     return sim_decode(T->S, comp, len, rows, cols, r, g, b, nullptr, nullptr, nullptr, nullptr, t);
+}
+
+// ---- tiled decode with the entropy decode split over the ranks: the steps of khg_tile_decode_map_dev ..
+// khg_tile_decode_inverse_dev on host memory.  The symbol planes are filled with a junk value first, so a symbol
+// that is neither decoded here nor received from its owner shows in the picture.
+int khgsim_tile_decode_map(void* h, const uint8_t* comp, size_t len, int rows, int cols, int rank, int nranks) {
+    SimTile* T = (SimTile*)h;
+    KhgTile t = {rank, nranks};
+    if (!khg_tile_ok(rows, t) || rows != T->rows || cols != T->cols || len < 60) return -1;
+    T->t = t;
+    T->comp.assign((len + 3) & ~(size_t)3, 0);
+    memcpy(T->comp.data(), comp, len);
+    T->comp_len = len;
+    khg_tile_active_blocks(T->comp.data(), T->nb);
+    const size_t ny = (size_t)rows * cols;
+    for (int p = 0; p < 3; ++p) memset(T->S.ws.sym[p], 0x7B, (p ? ny / 4 : ny) * 2);
+    KhgDecArgs d = T->dec_args();
+    for (int p = 0; p < 3; ++p) {
+        const uint32_t cap = (p < 2 ? d.blk0[p + 1] : d.nblocks) - d.blk0[p];
+        if (T->nb[p] > cap) T->nb[p] = cap;
+        memset(T->S.dws.blk + d.blk0[p], 0, (size_t)T->nb[p] * sizeof(KhgBlkInfo));
+    }
+    memset(T->S.ws.res, 0, sizeof(KhgResult));
+    khg_dec_header_body(d);
+    KhgDecTreeSmem* tsh = new KhgDecTreeSmem;
+    for (int p = 0; p < 3; ++p) khg_dec_tree_body(d, p, *tsh);
+    delete tsh;
+    KhgDecSmem<KHG_MAP_SMALL>* lsh = new KhgDecSmem<KHG_MAP_SMALL>;
+    KhgDecSmem<KHG_MAXOFF>* lsh2 = new KhgDecSmem<KHG_MAXOFF>;
+    const uint32_t grid = T->grid();
+    for (uint32_t b_ = 0; b_ < grid; ++b_) {
+        const uint32_t blk = khg_dec_dispatch_order(d, b_);
+        if (blk == ~0u) continue;
+        khg_dec_map_body<KHG_MAP_SMALL>(d, blk, *lsh);
+        khg_dec_map_body<KHG_MAXOFF>(d, blk, *lsh2);
+    }
+    delete lsh;
+    delete lsh2;
+    return 0;
+}
+
+size_t khgsim_tile_blk_words(void* h) {
+    SimTile* T = (SimTile*)h;
+    return ((size_t)T->nb[0] + T->nb[1] + T->nb[2]) * (sizeof(KhgBlkInfo) / 4);
+}
+
+static void sim_blk_copy(SimTile* T, uint32_t* words, bool get) {
+    KhgDecArgs d = T->dec_args();
+    size_t at = 0;
+    for (int p = 0; p < 3; ++p) {
+        const size_t bytes = (size_t)T->nb[p] * sizeof(KhgBlkInfo);
+        void* rec = T->S.dws.blk + d.blk0[p];
+        if (get) memcpy(words + at, rec, bytes);
+        else memcpy(rec, words + at, bytes);
+        at += bytes / 4;
+    }
+}
+void khgsim_tile_blk_get(void* h, uint32_t* words) { sim_blk_copy((SimTile*)h, words, true); }
+void khgsim_tile_blk_set(void* h, const uint32_t* words) { sim_blk_copy((SimTile*)h, (uint32_t*)words, false); }
+
+int khgsim_tile_decode_write(void* h, uint32_t* bounds) {
+    SimTile* T = (SimTile*)h;
+    KhgDecArgs d = T->dec_args();
+    const int n = T->t.nranks;
+    KhgDecChainSmem* ssh = new KhgDecChainSmem;
+    for (int p = 0; p < 3; ++p) khg_dec_chain_body(d, p, *ssh);
+    delete ssh;
+    KhgDecWriteSmem* wsh = new KhgDecWriteSmem;
+    const uint32_t grid = T->grid();
+    for (uint32_t b_ = 0; b_ < grid; ++b_) {
+        const uint32_t blk = khg_dec_dispatch_order(d, b_);
+        if (blk != ~0u) khg_dec_write_body(d, blk, *wsh);
+    }
+    delete wsh;
+    for (int p = 0; p < 3; ++p) {
+        uint32_t total = (uint32_t)T->S.ws.res->bits[p];
+        if (total > d.n[p]) total = d.n[p];
+        bounds[p * (n + 1) + n] = total;
+        for (int t = n - 1; t >= 0; --t) {
+            const uint32_t b = khg_part_begin(T->nb[p], (uint32_t)t, (uint32_t)n);
+            uint32_t v = b < T->nb[p] ? T->S.dws.blk[d.blk0[p] + b].out : 0xFFFFFFFFu;
+            if (v > bounds[p * (n + 1) + t + 1]) v = bounds[p * (n + 1) + t + 1];
+            bounds[p * (n + 1) + t] = v;
+        }
+    }
+    return T->S.ws.res->status;
+}
+
+int khgsim_tile_need_ranges(int rows, int cols, int rank, int nranks, int plane, uint32_t* ranges) {
+    KhgTile t = {rank, nranks};
+    uint32_t r[4][2];
+    const int n = khg_tile_need_ranges_impl(rows, cols, t, plane, r);
+    for (int i = 0; i < n; ++i) { ranges[2 * i] = r[i][0]; ranges[2 * i + 1] = r[i][1]; }
+    return n;
+}
+
+void khgsim_tile_sym_get(void* h, int plane, uint32_t first, uint32_t count, int16_t* dst) {
+    memcpy(dst, ((SimTile*)h)->S.ws.sym[plane] + first, (size_t)count * 2);
+}
+void khgsim_tile_sym_set(void* h, int plane, uint32_t first, uint32_t count, const int16_t* src) {
+    memcpy(((SimTile*)h)->S.ws.sym[plane] + first, src, (size_t)count * 2);
+}
+
+int khgsim_tile_decode_inverse(void* h, uint8_t* r, uint8_t* g, uint8_t* b) {
+    SimTile* T = (SimTile*)h;
+    sim_inverse(T->S, T->rows, T->cols, r, g, b, T->t, nullptr);
+    return T->S.ws.res->status;
 }
 
 double khgsim_ssim(const uint8_t* a, const uint8_t* b, int width, int height, double* blocks_out) {

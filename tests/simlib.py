@@ -73,6 +73,16 @@ def lib():
             getattr(L, "khgsim_tile_" + f).restype = None
         L.khgsim_tile_pack.argtypes = [_vp, _vp, C.c_size_t, C.POINTER(C.c_size_t)]
         L.khgsim_tile_decode.argtypes = [_vp, _vp, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]
+        L.khgsim_tile_decode_map.argtypes = [_vp, _vp, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.khgsim_tile_blk_words.argtypes = [_vp]
+        L.khgsim_tile_blk_words.restype = C.c_size_t
+        for f in ("blk_get", "blk_set", "decode_write"):
+            getattr(L, "khgsim_tile_" + f).argtypes = [_vp, _vp]
+        L.khgsim_tile_need_ranges.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]
+        for f in ("sym_get", "sym_set"):
+            getattr(L, "khgsim_tile_" + f).argtypes = [_vp, C.c_int, C.c_uint32, C.c_uint32, _vp]
+            getattr(L, "khgsim_tile_" + f).restype = None
+        L.khgsim_tile_decode_inverse.argtypes = [_vp, _vp, _vp, _vp]
         _lib = L
     return _lib
 
@@ -251,6 +261,47 @@ class SimTileBackend:
                                       out[1].data_ptr(), out[2].data_ptr())
         assert rc == 0, rc
         return out
+
+    # ---- decode with the entropy decode split over the ranks
+    def dec_map(self, comp, length, rows, cols, rank, world):
+        self.world, self.rank = world, rank
+        rc = lib().khgsim_tile_decode_map(self.h, comp.data_ptr(), length, rows, cols, rank, world)
+        assert rc == 0, rc
+
+    def blk_get(self):
+        L = lib()
+        words = self.torch.empty(L.khgsim_tile_blk_words(self.h), dtype=self.torch.int32)
+        L.khgsim_tile_blk_get(self.h, words.data_ptr())
+        return words
+
+    def blk_set(self, words):
+        lib().khgsim_tile_blk_set(self.h, words.contiguous().data_ptr())
+
+    def dec_write(self):
+        bounds = (C.c_uint32 * (3 * (self.world + 1)))()
+        self.write_status = lib().khgsim_tile_decode_write(self.h, bounds)
+        return list(bounds)
+
+    def need_ranges(self, rows, cols, rank, world, plane):
+        r = (C.c_uint32 * 8)()
+        n = lib().khgsim_tile_need_ranges(rows, cols, rank, world, plane, r)
+        return [(r[2 * i], r[2 * i + 1]) for i in range(n)]
+
+    def sym_get(self, plane, first, count):
+        t = self.torch.empty(count, dtype=self.torch.int16)
+        lib().khgsim_tile_sym_get(self.h, plane, first, count, t.data_ptr())
+        return t
+
+    def sym_set(self, plane, first, t):
+        lib().khgsim_tile_sym_set(self.h, plane, first, t.numel(), t.contiguous().data_ptr())
+
+    def sym_buffer(self, count):
+        return self.torch.empty(count, dtype=self.torch.int16)
+
+    def dec_inverse(self):
+        out = self.torch.empty((3, self.rows // self.world, self.cols), dtype=self.torch.uint8)
+        rc = lib().khgsim_tile_decode_inverse(self.h, out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr())
+        return out, rc
 
 
 def encode_ycbcr(y, cb, cr, lvl, want_coef=False):

@@ -45,10 +45,25 @@ def test_tiles_on_one_gpu_give_the_bytes_of_one_encoder(codec, shape, world, lvl
     assert res[0] == want
     assert all(r is None for r in res[1:])
     comp_t = torch.from_numpy(np.frombuffer(want + b"\0" * 8, np.uint8).copy()).cuda()
-    for rank in range(world):
-        tile = tiled.decode_tiled(tiled.HipTileBackend(ctxs[rank]), comp_t, len(want), rows, cols, rank, world)
+    for rank in range(world):  # every rank decodes the whole stream
+        tile = tiled.decode_tiled(tiled.HipTileBackend(ctxs[rank]), comp_t, len(want), rows, cols, rank, world,
+                                  split=False)
         r0, r1 = tiled.tile_rows(rows, rank, world)
         assert torch.equal(tile, full[:, r0:r1])
+
+    # every rank decodes 1/world of each plane's stream; records all-reduced, symbols sent point to point.  The
+    # workspaces are filled with junk first: a symbol that is not exchanged shows in the picture.
+    for c in ctxs:
+        c.debug_poison(0x7B)
+
+    def dec_fn(rank, coll):
+        tile = tiled.decode_tiled(tiled.HipTileBackend(ctxs[rank]), comp_t, len(want), rows, cols, rank, world, coll=coll)
+        torch.cuda.synchronize()
+        return tile
+
+    for rank, tile in enumerate(run_ranks(world, dec_fn)):
+        r0, r1 = tiled.tile_rows(rows, rank, world)
+        assert torch.equal(tile, full[:, r0:r1]), rank
 
 
 def test_tile_generator_matches_the_frame(codec):
@@ -83,6 +98,16 @@ class _HostStaged:
     def reduce_sum(self, t, dst):
         self._via_host(t, lambda h: dist.reduce(h, dst=dst, op=dist.ReduceOp.SUM))
 
+    def exchange(self, sends, recvs):
+        hs = [(dst, t.cpu()) for dst, t in sends]
+        hr = [(src, torch.empty(t.shape, dtype=t.dtype)) for src, t in recvs]
+        ops = [dist.P2POp(dist.isend, t, dst) for dst, t in hs] + [dist.P2POp(dist.irecv, t, src) for src, t in hr]
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        for (_, t), (_, h) in zip(recvs, hr):
+            t.copy_(h)
+
 
 def _free_port():
     s = socket.socket()
@@ -107,13 +132,65 @@ def _gloo_gpu_rank(rank, world, port, rows, cols, lvl, out_path):
     if rank == 0:
         with open(out_path, "wb") as f:
             f.write(comp.cpu().numpy().tobytes())
+    # split decode over the two processes
+    length = torch.tensor([comp.numel() if rank == 0 else 0], dtype=torch.int64)
+    dist.broadcast(length, src=0)
+    n = int(length.item())
+    full = torch.zeros((n + 11) & ~3, dtype=torch.uint8)
+    if rank == 0:
+        full[:n] = comp.cpu()
+    dist.broadcast(full, src=0)
+    tile = tiled.decode_tiled(tiled.HipTileBackend(c), full.cuda(), n, rows, cols, rank, world, coll=_HostStaged())
+    np.save(out_path + ".tile%d.npy" % rank, tile.cpu().numpy())
     dist.barrier()
     dist.destroy_process_group()
 
 
 def test_two_processes_on_one_gpu(codec, tmp_path):
+    from khugle_amd import tiled
     rows, cols, lvl, world = 512, 768, 1, 2
     out = str(tmp_path / "tiled.comp")
     mp.spawn(_gloo_gpu_rank, args=(world, _free_port(), rows, cols, lvl, out), nprocs=world, join=True)
     want = codec.encode(codec.synth_dev(rows, cols, 2025, 9).cpu().numpy(), lvl)
     assert open(out, "rb").read() == want
+    pixels = codec.decode(want)
+    for rank in range(world):
+        r0, r1 = tiled.tile_rows(rows, rank, world)
+        assert np.array_equal(np.load(out + ".tile%d.npy" % rank), pixels[:, r0:r1])
+
+
+def test_full_size_image_in_eight_tiles(codec):
+    """One 8192 x 8192 image over eight ranks (eight contexts on this GPU, collectives between threads): the file and
+    the picture of the single-tile path, with the entropy decode split over the ranks."""
+    from khugle_amd import Codec, tiled
+    from tiledlib import run_ranks
+    side, world, lvl = 8192, 8, 1
+    one = Codec(side, side)
+    frame = one.synth_dev(side, side, 2025, 0)
+    out = torch.zeros(one.comp_bound(side, side), dtype=torch.uint8, device="cuda")
+    one.encode_dev(frame, lvl, out)
+    n = one.encode_result()
+    dec = torch.empty((3, side, side), dtype=torch.uint8, device="cuda")
+    one.decode_dev(out, n, side, side, dec)
+    assert one.last_status() == 0
+    ctxs = [Codec(side, side) for _ in range(world)]
+
+    def rank_fn(rank, coll):
+        be = tiled.HipTileBackend(ctxs[rank])
+        comp = tiled.encode_tiled(be, _strip(frame, side, rank, world), side, side, lvl, rank, world, coll=coll)
+        torch.cuda.synchronize()
+        return comp
+
+    res = run_ranks(world, rank_fn)
+    assert res[0].numel() == n and torch.equal(res[0], out[:n])
+    full = torch.zeros((n + 11) & ~3, dtype=torch.uint8, device="cuda")
+    full[:n] = out[:n]
+
+    def dec_fn(rank, coll):
+        tile = tiled.decode_tiled(tiled.HipTileBackend(ctxs[rank]), full, n, side, side, rank, world, coll=coll)
+        torch.cuda.synchronize()
+        return tile
+
+    for rank, tile in enumerate(run_ranks(world, dec_fn)):
+        r0, r1 = tiled.tile_rows(side, rank, world)
+        assert torch.equal(tile, dec[:, r0:r1]), rank

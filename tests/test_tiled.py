@@ -41,14 +41,24 @@ def test_tiles_give_the_bytes_of_one_encoder(shape, world, lvl):
     res = run_ranks(world, rank_fn)
     assert res[0] == want
     assert all(r is None for r in res[1:])
-    # decode: every rank reconstructs its rows from the whole file
+    # decode: every rank reconstructs its rows from the whole file, decoding all of the stream itself ...
     full = O.decode(want)
     comp_t = torch.from_numpy(np.frombuffer(want + b"\0" * 8, np.uint8).copy())
     for rank in range(world):
         be = S.SimTileBackend(rows, cols)
-        tile = tiled.decode_tiled(be, comp_t, len(want), rows, cols, rank, world).numpy()
+        tile = tiled.decode_tiled(be, comp_t, len(want), rows, cols, rank, world, split=False).numpy()
         r0, r1 = tiled.tile_rows(rows, rank, world)
         assert np.array_equal(tile, full[:, r0:r1])
+
+    # ... or 1/world of every plane's stream, with the workgroup records summed over the ranks and the decoded
+    # symbols sent to the ranks whose rows need them (the simulator fills the symbol planes with junk first)
+    def dec_fn(rank, coll):
+        be = S.SimTileBackend(rows, cols)
+        return tiled.decode_tiled(be, comp_t, len(want), rows, cols, rank, world, coll=coll).numpy()
+
+    for rank, tile in enumerate(run_ranks(world, dec_fn)):
+        r0, r1 = tiled.tile_rows(rows, rank, world)
+        assert np.array_equal(tile, full[:, r0:r1]), rank
 
 
 def _free_port():
@@ -78,6 +88,17 @@ def _gloo_rank(rank, world, port, rows, cols, lvl, out_path):
             f.write(comp.numpy().tobytes())
     else:
         assert comp is None
+    # decode over the same ranks: the file goes to every rank, each entropy-decodes half of every plane's stream,
+    # the workgroup records are all-reduced and the symbols travel point to point
+    length = torch.tensor([comp.numel() if rank == 0 else 0], dtype=torch.int64)
+    dist.broadcast(length, src=0)
+    n = int(length.item())
+    full = torch.zeros((n + 11) & ~3, dtype=torch.uint8)
+    if rank == 0:
+        full[:n] = comp
+    dist.broadcast(full, src=0)
+    tile = tiled.decode_tiled(S.SimTileBackend(rows, cols), full, n, rows, cols, rank, world)
+    np.save(out_path + ".tile%d.npy" % rank, tile.numpy())
     dist.barrier()
     dist.destroy_process_group()
 
@@ -87,8 +108,52 @@ def test_two_gloo_ranks_exchange_halos_and_histograms(tmp_path):
     out = str(tmp_path / "tiled.comp")
     mp.spawn(_gloo_rank, args=(world, _free_port(), rows, cols, lvl, out), nprocs=world, join=True)
     import oracle_py as O
+    from khugle_amd import tiled
     from khugle_amd.synth import synth_frame
-    assert open(out, "rb").read() == O.encode(synth_frame(rows, cols, 11, 0), lvl)
+    want = O.encode(synth_frame(rows, cols, 11, 0), lvl)
+    assert open(out, "rb").read() == want
+    pixels = O.decode(want)
+    for rank in range(world):
+        r0, r1 = tiled.tile_rows(rows, rank, world)
+        assert np.array_equal(np.load(out + ".tile%d.npy" % rank), pixels[:, r0:r1])
+
+
+def _gloo_rank_damaged(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from khugle_amd import tiled
+    from khugle_amd.lib import KhgError
+    from khugle_amd.synth import synth_frame
+    import oracle_py as O
+    import simlib as S
+    rows, cols = 128, 96
+    comp = bytearray(O.encode(synth_frame(rows, cols, 11, 0), 1))
+    # the luma table's first symbol out of the int16 range: the tree kernel flags it on every rank
+    k = [int.from_bytes(comp[12 + 4 * i:16 + 4 * i], "little") for i in range(3)]
+    tab = len(comp) - 8 * sum(k)
+    comp[tab + 4:tab + 8] = (70000).to_bytes(4, "little")
+    full = torch.from_numpy(np.frombuffer(bytes(comp) + b"\0" * 8, np.uint8).copy())
+    try:
+        tiled.decode_tiled(S.SimTileBackend(rows, cols), full, len(comp), rows, cols, rank, world)
+        outcome = "returned"
+    except KhgError as e:
+        outcome = "raised %d" % e.code
+    with open(os.path.join(out_dir, "rank%d.txt" % rank), "w") as f:
+        f.write(outcome)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_a_damaged_file_fails_every_rank_of_a_split_decode(tmp_path):
+    world = 2
+    ctx = mp.spawn(_gloo_rank_damaged, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=False)
+    import time
+    deadline = time.time() + 120
+    while not ctx.join(timeout=5):
+        assert time.time() < deadline, "ranks hung"
+    for r in range(world):
+        assert open(os.path.join(str(tmp_path), "rank%d.txt" % r)).read() == "raised -4"
 
 
 def _gloo_rank_failing(rank, world, port, out_dir):

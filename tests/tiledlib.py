@@ -37,6 +37,18 @@ class ThreadCollectives:
         if self.rank == dst:
             t.copy_(torch.stack(parts).sum(0).to(t.dtype))
 
+    def exchange(self, sends, recvs):
+        """Point to point: between two ranks the tensors are matched in list order."""
+        self.sh.slots[self.rank] = sends
+        self.sh.barrier.wait()
+        taken = {}
+        for src, buf in recvs:
+            i = taken.get(src, 0)
+            mine = [t for dst, t in self.sh.slots[src] if dst == self.rank]
+            buf.copy_(mine[i].to(buf.device))
+            taken[src] = i + 1
+        self.sh.barrier.wait()
+
 
 def run_ranks(world, fn):
     """fn(rank, coll) on `world` threads; returns the list of results, re-raising the first failure."""
