@@ -24,6 +24,18 @@
 #define KHG_TOUCH_DONE(reg) ((void)(reg))
 #define KHG_UNROLL
 #define KHG_NOUNROLL
+// Workgroup collective (256 threads, like KHG_BARRIER not inside KHG_FOR_THREADS): excl[t] = val[0] + .. + val[t-1],
+// total = the sum of all; lds4: four LDS words nobody else touches until the next barrier.
+#define KHG_WG_EXCL_SCAN(excl, val, lds4, total)   \
+    {                                              \
+        uint32_t run_ = 0;                         \
+        for (int t_ = 0; t_ < 256; ++t_) {         \
+            const uint32_t v_ = (val)[t_];         \
+            (excl)[t_] = run_;                     \
+            run_ += v_;                            \
+        }                                          \
+        (total) = run_;                            \
+    }
 static inline uint32_t khg_atomic_add(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o + v; return o; }
 static inline uint32_t khg_atomic_min(uint32_t* p, uint32_t v) { uint32_t o = *p; if (v < o) *p = v; return o; }
 static inline uint32_t khg_atomic_or(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o | v; return o; }
@@ -53,6 +65,35 @@ static inline void khg_atomic_max64(unsigned long long* p, unsigned long long v)
 #define KHG_TOUCH_DONE(reg) asm volatile("s_waitcnt vmcnt(0)" : "+v"(reg) : : "memory")
 #define KHG_UNROLL _Pragma("unroll")
 #define KHG_NOUNROLL _Pragma("nounroll")
+// Inclusive prefix sum over the lanes of a wave.
+__device__ __forceinline__ uint32_t khg_wave_incl_scan(uint32_t v)
+{
+    const int lane = (int)(threadIdx.x & 63u);
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = (uint32_t)__shfl_up((int)v, d, 64);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+// Workgroup collective (256 threads, like KHG_BARRIER not inside KHG_FOR_THREADS): excl[0] = the sum of val of all
+// lower threads, total = the sum of all; lds4: four LDS words nobody else touches until the next barrier.
+#define KHG_WG_EXCL_SCAN(excl, val, lds4, total)                      \
+    {                                                                 \
+        const uint32_t inc_ = khg_wave_incl_scan((val)[0]);           \
+        const uint32_t w_ = threadIdx.x >> 6;                         \
+        if ((threadIdx.x & 63u) == 63u) (lds4)[w_] = inc_;            \
+        __syncthreads();                                              \
+        uint32_t base_ = 0, tot_ = 0;                                 \
+        _Pragma("unroll") for (uint32_t i_ = 0; i_ < 4; ++i_)        \
+        {                                                             \
+            const uint32_t s_ = (lds4)[i_];                           \
+            base_ += i_ < w_ ? s_ : 0u;                               \
+            tot_ += s_;                                               \
+        }                                                             \
+        (excl)[0] = base_ + inc_ - (val)[0];                          \
+        (total) = tot_;                                               \
+    }
 __device__ __forceinline__ uint32_t khg_atomic_add(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
 __device__ __forceinline__ uint32_t khg_atomic_min(uint32_t* p, uint32_t v) { return atomicMin(p, v); }
 __device__ __forceinline__ uint32_t khg_atomic_or(uint32_t* p, uint32_t v) { return atomicOr(p, v); }

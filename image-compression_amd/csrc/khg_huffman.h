@@ -385,7 +385,7 @@ KHG_DEV int khg_load8(const int16_t* sym, uint32_t s0, uint32_t end, int16_t v[8
 enum { KHG_HOT_SYMS = 256 };
 
 struct KhgLensSmem {
-    uint32_t part[256];
+    uint32_t wave[4];
     uint8_t len8[KHG_HOT_SYMS];
 };
 
@@ -399,6 +399,7 @@ KHG_DEV void khg_lens_body(const KhgEncArgs& a, uint32_t chunk, KhgLensSmem& sh)
     const uint32_t base = ck.sym0, end = ck.sym0 + ck.nsym;
     int16_t vs[KHG_NSLOT(256)][8];
     int nvs[KHG_NSLOT(256)];
+    uint32_t bitsv[KHG_NSLOT(256)], excl[KHG_NSLOT(256)];
     KHG_FOR_THREADS(256)
     {
         sh.len8[tid] = (uint8_t)(ctab[KHG_SYM_BIAS - KHG_HOT_SYMS / 2 + tid] >> 56);
@@ -410,31 +411,26 @@ KHG_DEV void khg_lens_body(const KhgEncArgs& a, uint32_t chunk, KhgLensSmem& sh)
         uint32_t bits = 0;
         const int16_t* v = vs[KHG_SLOT];
         const int nv = nvs[KHG_SLOT];
+        KHG_UNROLL
         for (int i = 0; i < 8; ++i) {
             if (i < nv) {
                 const uint32_t h = (uint32_t)(v[i] + KHG_HOT_SYMS / 2);
-                bits += h < (uint32_t)KHG_HOT_SYMS ? sh.len8[h] : (uint32_t)(ctab[v[i] + KHG_SYM_BIAS] >> 56);
+                uint32_t len = sh.len8[h & (KHG_HOT_SYMS - 1)];
+                if (h >= (uint32_t)KHG_HOT_SYMS) {
+                    KHG_OPAQUE(len);  // the LDS load stays a load of its own (not one flat load of a selected address)
+                    len = (uint32_t)(ctab[v[i] + KHG_SYM_BIAS] >> 56);
+                }
+                bits += len;
             }
         }
-        sh.part[tid] = bits;
+        bitsv[KHG_SLOT] = bits;
     }
-    KHG_BARRIER();
+    uint32_t total;
+    KHG_WG_EXCL_SCAN(excl, bitsv, sh.wave, total)
     KHG_FOR_THREADS(256)
     {
-        if (tid < 16) {
-            uint32_t s = 0;
-            for (int i = 0; i < 16; ++i) s += sh.part[tid * 16 + i];
-            sh.part[tid * 16] = s;
-        }
-    }
-    KHG_BARRIER();
-    KHG_FOR_THREADS(256)
-    {
-        if (tid == 0) {
-            uint32_t s = 0;
-            for (int i = 0; i < 16; ++i) s += sh.part[i * 16];
-            a.chunk_bits[chunk] = s;
-        }
+        (void)excl[KHG_SLOT];
+        if (tid == 0) a.chunk_bits[chunk] = total;
     }
 }
 
@@ -600,14 +596,44 @@ enum { KHG_PACK_WORDS = (31 + KHG_CHUNK * KHG_MAX_CODE_BITS + 31) / 32 + 2 };
 
 struct KhgPackSmem {
     uint32_t words[KHG_PACK_WORDS];
-    uint32_t part[256];
-    uint32_t grp[16];
+    uint32_t wave[4];
     uint64_t hot[KHG_HOT_SYMS];  // see KHG_HOT_SYMS
 };
 
-// One chunk per workgroup, 8 symbols per thread.  The chunk's bits are assembled in LDS in
-// big-endian 32-bit words aligned to the output word holding its first bit, then written out;
-// the first and last word may be shared with neighbouring chunks and are OR-merged.
+// Table entry of symbol v: (length << 56) | code.
+KHG_DEV uint64_t khg_pack_code(const KhgPackSmem& sh, const uint64_t* ctab, int v)
+{
+    // the LDS entry is fetched unconditionally (index wrapped) and replaced on the rare path: a select between
+    // an LDS and a global address would turn both into one flat load
+    const uint32_t h = (uint32_t)(v + KHG_HOT_SYMS / 2);
+    uint64_t c = sh.hot[h & (KHG_HOT_SYMS - 1)];
+    if (h >= (uint32_t)KHG_HOT_SYMS) {
+        KHG_OPAQUE(c);  // the LDS load stays a load of its own
+        c = ctab[v + KHG_SYM_BIAS];
+    }
+    return c;
+}
+
+// ORs the n <= 64 bits of `bits` (right-aligned) into the workgroup's word buffer at bit position pos (first
+// stream bit = most significant bit of a word).  Zero bits set nothing, so an all-zero string costs nothing.
+KHG_DEV void khg_pack_put(uint32_t* words, uint32_t pos, uint64_t bits, uint32_t n)
+{
+    if (n == 0 || bits == 0) return;
+    const uint64_t v = bits << (64 - n);  // left-aligned
+    const uint32_t w = pos >> 5, s = pos & 31;
+    const uint32_t hi = (uint32_t)(v >> 32), lo = (uint32_t)v;
+    if (hi >> s) khg_atomic_or(&words[w], hi >> s);
+    if (s + n > 32) {
+        const uint32_t mid = s ? (hi << (32 - s)) | (lo >> s) : lo;
+        if (mid) khg_atomic_or(&words[w + 1], mid);
+        if (s + n > 64 && (lo << (32 - s))) khg_atomic_or(&words[w + 2], lo << (32 - s));
+    }
+}
+
+// One chunk per workgroup, 8 symbols per thread.  A thread first strings its eight codes together in a register
+// (nearly always 64 bits or fewer); the chunk's bits are assembled in LDS in big-endian 32-bit words aligned to the
+// output word holding its first bit, then written out; the first and last word may be shared with neighbouring
+// chunks and are OR-merged.
 KHG_DEV void khg_pack_body(const KhgEncArgs& a, uint32_t chunk, KhgPackSmem& sh)
 {
     if (!a.res->ok_to_pack) return;
@@ -622,7 +648,8 @@ KHG_DEV void khg_pack_body(const KhgEncArgs& a, uint32_t chunk, KhgPackSmem& sh)
     const uint32_t lead = (uint32_t)(off & 31);
     const uint32_t nw = (lead + bits + 31) >> 5;
 
-    uint64_t code[KHG_NSLOT(256)][8];
+    uint64_t acc[KHG_NSLOT(256)];
+    uint32_t tbs[KHG_NSLOT(256)], excl[KHG_NSLOT(256)];
     int16_t vs[KHG_NSLOT(256)][8];
     int nvs[KHG_NSLOT(256)];
     KHG_FOR_THREADS(256)
@@ -635,63 +662,41 @@ KHG_DEV void khg_pack_body(const KhgEncArgs& a, uint32_t chunk, KhgPackSmem& sh)
     KHG_FOR_THREADS(256)
     {
         uint32_t tb = 0;
+        uint64_t ac = 0;
         const int16_t* v = vs[KHG_SLOT];
         const int nv = nvs[KHG_SLOT];
+        KHG_UNROLL
         for (int i = 0; i < 8; ++i) {
-            uint64_t c = 0;
             if (i < nv) {
-                const uint32_t h = (uint32_t)(v[i] + KHG_HOT_SYMS / 2);
-                c = h < (uint32_t)KHG_HOT_SYMS ? sh.hot[h] : ctab[v[i] + KHG_SYM_BIAS];
-            }
-            code[KHG_SLOT][i] = c;
-            tb += (uint32_t)(c >> 56);
-        }
-        sh.part[tid] = tb;
-    }
-    KHG_BARRIER();
-    KHG_FOR_THREADS(256)
-    {
-        if (tid < 16) {  // exclusive scan inside each group of 16 threads
-            uint32_t run = 0;
-            for (int i = 0; i < 16; ++i) {
-                uint32_t v = sh.part[tid * 16 + i];
-                sh.part[tid * 16 + i] = run;
-                run += v;
-            }
-            sh.grp[tid] = run;
-        }
-    }
-    KHG_BARRIER();
-    KHG_FOR_THREADS(256)
-    {
-        if (tid == 0) {
-            uint32_t run = 0;
-            for (int i = 0; i < 16; ++i) {
-                uint32_t v = sh.grp[i];
-                sh.grp[i] = run;
-                run += v;
+                const uint64_t c = khg_pack_code(sh, ctab, v[i]);
+                const uint32_t len = (uint32_t)(c >> 56);
+                ac = (ac << len) | (c & 0x00FFFFFFFFFFFFFFull);  // meaningful while tb <= 64 (len <= 56)
+                tb += len;
             }
         }
+        acc[KHG_SLOT] = ac;
+        tbs[KHG_SLOT] = tb;
     }
-    KHG_BARRIER();
+    uint32_t total;
+    KHG_WG_EXCL_SCAN(excl, tbs, sh.wave, total)
     KHG_FOR_THREADS(256)
     {
-        uint32_t pos = lead + sh.grp[tid >> 4] + sh.part[tid];
-        for (int i = 0; i < 8; ++i) {
-            uint64_t c = code[KHG_SLOT][i];
-            uint32_t len = (uint32_t)(c >> 56);
-            if (len) {
-                uint64_t v = c << (64 - len);  // left-aligned code (bits above len fall off)
-                uint32_t w = pos >> 5, sh_ = pos & 31;
-                uint32_t hi = (uint32_t)(v >> 32), lo = (uint32_t)v;
-                // an all-zero code (normally the most frequent symbol's 1-bit code) sets nothing
-                if (hi >> sh_) khg_atomic_or(&sh.words[w], hi >> sh_);
-                if (v != 0 && sh_ + len > 32) {
-                    uint32_t mid = sh_ ? (hi << (32 - sh_)) | (lo >> sh_) : lo;
-                    khg_atomic_or(&sh.words[w + 1], mid);
-                    if (sh_ + len > 64) khg_atomic_or(&sh.words[w + 2], lo << (32 - sh_));
+        (void)total;
+        uint32_t pos = lead + excl[KHG_SLOT];
+        const uint32_t tb = tbs[KHG_SLOT];
+        if (tb <= 64) {
+            khg_pack_put(sh.words, pos, acc[KHG_SLOT], tb);
+        } else {  // long codes: one at a time
+            const int16_t* v = vs[KHG_SLOT];
+            const int nv = nvs[KHG_SLOT];
+            KHG_UNROLL
+            for (int i = 0; i < 8; ++i) {  // constant indices: the symbols stay in registers
+                if (i < nv) {
+                    const uint64_t c = khg_pack_code(sh, ctab, v[i]);
+                    const uint32_t len = (uint32_t)(c >> 56);
+                    khg_pack_put(sh.words, pos, c & 0x00FFFFFFFFFFFFFFull, len);
+                    pos += len;
                 }
-                pos += len;
             }
         }
     }

@@ -74,12 +74,24 @@ KHG_DEV void khg_ssim_mean_body(const KhgSsimMeanArgs& a, KhgSsimMeanSmem& sh)
             if (tid == 0) {
                 double s = sh.sum;
                 int i = 0;
-                for (; i + 8 <= n; i += 8) {  // eight values fetched ahead of the chain of additions
-                    double t[8];
+                // the additions form one dependent chain (the reference's order); the next sixteen values are
+                // requested from LDS before the current sixteen are added, so the chain never waits for a fetch
+                double t[16];
+                if (n >= 16) {
                     KHG_UNROLL
-                    for (int u = 0; u < 8; ++u) t[u] = sh.v[i + u];
+                    for (int u = 0; u < 16; ++u) t[u] = sh.v[u];
+                    for (; i + 32 <= n; i += 16) {
+                        double nx[16];
+                        KHG_UNROLL
+                        for (int u = 0; u < 16; ++u) nx[u] = sh.v[i + 16 + u];
+                        KHG_UNROLL
+                        for (int u = 0; u < 16; ++u) s += t[u];
+                        KHG_UNROLL
+                        for (int u = 0; u < 16; ++u) t[u] = nx[u];
+                    }
                     KHG_UNROLL
-                    for (int u = 0; u < 8; ++u) s += t[u];
+                    for (int u = 0; u < 16; ++u) s += t[u];
+                    i += 16;
                 }
                 for (; i < n; ++i) s += sh.v[i];
                 sh.sum = s;
