@@ -151,21 +151,6 @@ KHG_DEV double khg_div_const(double x, double c, double rc)
     return khg_fma(r, rc, q);
 }
 
-// round(c / div) of Compress.h:218 from rdiv = RN(1/div), when that is safe: t = c*rdiv is within 2^-51
-// (relative) of the exact quotient, so both round to the same integer unless t sits that close to a
-// half-integer.  Returns false (caller must divide) for anything within 2^-31 of one -- which also covers every
-// |t| >= 2^30, NaN and infinity, so a true result always converts to int exactly.
-KHG_DEV bool khg_round_quot_fast(double c, double rdiv, double* n_out)
-{
-    double t = c * rdiv;
-    double n = __builtin_rint(t);  // ties aside (the caller divides for those), nearest-even == half-away
-    *n_out = n;
-    return 0.5 - fabs(t - n) > fabs(t) * 0x1p-31;
-}
-
-// Whole-sample symmetric extension of index i onto [0, n), any i (n even, >= 2).
-// The reference's boundary lines x[n-1] += 2*a*x[n-2] and x[0] += 2*a*x[1] (DWT.h:18,26,34,42)
-// equal the interior formula on this extension bit for bit: 2*a*x == a*(x + x) exactly.
 // Rows [*r0, *r1) of segment `seg` of `nseg` over the even row range [begin, end): the row pairs are dealt out evenly,
 // segments differ by at most one pair.
 KHG_DEV void khg_segment_rows(int begin, int end, int nseg, int seg, int* r0, int* r1)
@@ -175,6 +160,9 @@ KHG_DEV void khg_segment_rows(int begin, int end, int nseg, int seg, int* r0, in
     *r1 = begin + 2 * (int)(hp * (seg + 1) / nseg);
 }
 
+// Whole-sample symmetric extension of index i onto [0, n), any i (n even, >= 2).
+// The reference's boundary lines x[n-1] += 2*a*x[n-2] and x[0] += 2*a*x[1] (DWT.h:18,26,34,42)
+// equal the interior formula on this extension bit for bit: 2*a*x == a*(x + x) exactly.
 KHG_DEV int khg_reflect(int i, int n)
 {
     if ((unsigned)i < (unsigned)n) return i;

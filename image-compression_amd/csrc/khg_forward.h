@@ -447,16 +447,6 @@ KHG_DEV void khg_quant_emit(const KhgFwdArgs& a, const KhgFwdPlane& pl, uint32_t
     for (int i = 0; i < NS; ++i) *(int16_t*)((char*)pl.sym + (so + boff[i])) = (int16_t)q[i];
 }
 
-// First pair held by lane 0 of strip s of a plane with np pairs: two halo pairs before the strip's first output
-// pair, except that the first strip starts at pair 0 and the last one ends at pair np-1 (see the file comment).
-KHG_DEV int khg_strip_first_pair(int s, int np)
-{
-    int p0 = KHG_STRIP_PAIRS * s - 2;
-    const int last = np - KHG_LANES;
-    if (p0 > last) p0 = last;
-    return p0 < 0 ? 0 : p0;
-}
-
 // Finished, unscaled outputs (s2, d2) of row pair k of the lane's low-half column (L) and high-half column (H):
 // scale, store / quantise.  rd: this position's reciprocal divisors per band slot; so, llo: byte offsets of
 // position (k, pair) in the symbol plane and in the LL buffer.

@@ -140,20 +140,25 @@ KHG_DEV void khg_inv_wg_body(const KhgInvArgs& a, const KhgInvPlane& pl, int wgl
     const KhgQuant& qc = pl.q[lvl];
     const int swg = wgl % pl.nstrip_wg, seg = wgl / pl.nstrip_wg;
     const int np = pl.pw / 2, hh = pl.ph / 2, hw = pl.pw / 2;
-    const int nstrips = (np + KHG_STRIP_PAIRS - 1) / KHG_STRIP_PAIRS;
     int r0, r1;
     khg_segment_rows(pl.row_begin, pl.row_end, pl.nseg, seg, &r0, &r1);
     const int k0 = r0 / 2, k1 = r1 / 2;
-    const int P0 = khg_strip_first_pair(swg * KHG_WG_STRIPS, np);  // first pair of the workgroup
+    const int P0 = KHG_STRIP_PAIRS * KHG_WG_STRIPS * swg - 2;  // pair held by the workgroup's first lane
     // packed rows this segment reads (reflections included) lie in [klo, klo + nk)
     const int klo = k0 - 4 < 0 ? 0 : k0 - 4;
     const int khi = k1 + 3 > hh - 1 ? hh - 1 : k1 + 3;
 
     KhgILift colL[KHG_NSLOT(256)], colH[KHG_NSLOT(256)];
     KhgInvRaw raws[KHG_NSLOT(256)];
-    int pairs[KHG_NSLOT(256)];
-    int flags[KHG_NSLOT(256)];  // bit 0: lane outputs its pair; bit 1: holds the plane's first pair; bit 2: its last
-    int edges[KHG_NSLOT(256)];  // wave-uniform: bit 1 / bit 2: a lane of this wave holds the first / last pair
+    int pairs[KHG_NSLOT(256)];  // the lane's pair, clamped to the strip's output pairs
+    // Columns the lane's low-pass and high-pass samples are read from.  Lanes hold pairs 60 s - 2 .. 60 s + 61 of the
+    // interleaved row; a pair outside the plane is the whole-sample mirror image (x[-i] = x[i], x[n-1+i] =
+    // x[n-1-i]) of samples inside, i.e. a low-pass sample of one column and a high-pass sample of another.  Lifting
+    // preserves the symmetry, so the interior formula gives what the reference's edge lines give (DWT.h:75-100)
+    // and the row pass needs no edge case.
+    int colsL[KHG_NSLOT(256)], colsH[KHG_NSLOT(256)];
+    int uL[KHG_NSLOT(256)], uH[KHG_NSLOT(256)];  // their offsets in the workgroup's divisor diagonals
+    bool outl[KHG_NSLOT(256)];  // the lane outputs its pair
     double LO[2][KHG_NSLOT(256)], HI[2][KHG_NSLOT(256)], S1[2][KHG_NSLOT(256)], D1[2][KHG_NSLOT(256)],
         S0[2][KHG_NSLOT(256)], X[2][KHG_NSLOT(256)], CB[KHG_NSLOT(256)], CR[KHG_NSLOT(256)];
 
@@ -165,12 +170,17 @@ KHG_DEV void khg_inv_wg_body(const KhgInvArgs& a, const KhgInvPlane& pl, int wgl
     KHG_FOR_THREADS(256)
     {
         const int lane = tid & 63, s = swg * KHG_WG_STRIPS + KHG_UNIFORM(tid >> 6);
-        const int p0 = khg_strip_first_pair(s, np);
-        const int p = p0 + lane;
         const int v0 = KHG_STRIP_PAIRS * s, v1 = v0 + KHG_STRIP_PAIRS < np ? v0 + KHG_STRIP_PAIRS : np;
-        pairs[KHG_SLOT] = p < np ? p : np - 1;
-        flags[KHG_SLOT] = (s < nstrips && p >= v0 && p < v1 ? 1 : 0) | (p == 0 ? 2 : 0) | (p == np - 1 ? 4 : 0);
-        edges[KHG_SLOT] = (p0 == 0 ? 2 : 0) | (p0 + KHG_LANES >= np ? 4 : 0);
+        const int p = v0 - 2 + lane;
+        outl[KHG_SLOT] = p >= v0 && p < v1;  // a wave beyond the last strip loads and computes without output
+        pairs[KHG_SLOT] = p < v0 ? v0 : (p > v0 + KHG_STRIP_PAIRS - 1 ? v0 + KHG_STRIP_PAIRS - 1 : p);
+        colsL[KHG_SLOT] = khg_reflect(2 * p, pl.pw) >> 1;
+        colsH[KHG_SLOT] = khg_reflect(2 * p + 1, pl.pw) >> 1;
+        const int umax = KHG_WG_STRIPS * KHG_STRIP_PAIRS + 3;  // lanes beyond the plane: any entry of the table
+        int u = colsL[KHG_SLOT] - P0;
+        uL[KHG_SLOT] = u < 0 ? 0 : (u > umax ? umax : u);
+        u = colsH[KHG_SLOT] - P0;
+        uH[KHG_SLOT] = u < 0 ? 0 : (u > umax ? umax : u);
         const KhgILift z = {0, 0, 0, 0};
         colL[KHG_SLOT] = z;
         colH[KHG_SLOT] = z;
@@ -191,18 +201,18 @@ KHG_DEV void khg_inv_wg_body(const KhgInvArgs& a, const KhgInvPlane& pl, int wgl
 #define KHG_INV_FETCH(raw, j)                                                                               \
     {                                                                                                       \
         const int ke_ = KHG_INV_KE(j), ko_ = hh + KHG_INV_KO(j);                                            \
-        const uint32_t oe_ = (uint32_t)ke_ * (uint32_t)pl.sym_pitch + (uint32_t)pairs[KHG_SLOT];            \
-        const uint32_t oo_ = (uint32_t)ko_ * (uint32_t)pl.sym_pitch + (uint32_t)pairs[KHG_SLOT];            \
+        const uint32_t oe_ = (uint32_t)ke_ * (uint32_t)pl.sym_pitch, oo_ = (uint32_t)ko_ * (uint32_t)pl.sym_pitch; \
+        const uint32_t cl_ = (uint32_t)colsL[KHG_SLOT], ch_ = (uint32_t)(hw + colsH[KHG_SLOT]);             \
         if (LEVEL == 1) {                                                                                   \
-            (raw).ll = pl.ll[(uint32_t)ke_ * (uint32_t)pl.ll_pitch + (uint32_t)pairs[KHG_SLOT]];            \
+            (raw).ll = pl.ll[(uint32_t)ke_ * (uint32_t)pl.ll_pitch + cl_];                                  \
             (raw).q[0] = 0;                                                                                 \
         } else {                                                                                            \
             (raw).ll = 0.0;                                                                                 \
-            (raw).q[0] = pl.sym[oe_];                                                                       \
+            (raw).q[0] = pl.sym[oe_ + cl_];                                                                 \
         }                                                                                                   \
-        (raw).q[1] = pl.sym[oe_ + (uint32_t)hw];                                                            \
-        (raw).q[2] = pl.sym[oo_];                                                                           \
-        (raw).q[3] = pl.sym[oo_ + (uint32_t)hw];                                                            \
+        (raw).q[1] = pl.sym[oe_ + ch_];                                                                     \
+        (raw).q[2] = pl.sym[oo_ + cl_];                                                                     \
+        (raw).q[3] = pl.sym[oo_ + ch_];                                                                     \
         if (RGB) {                                                                                          \
             int m_ = (j) - 2;                                                                               \
             m_ = m_ < 0 ? 0 : (m_ > hh - 1 ? hh - 1 : m_);                                                  \
@@ -220,18 +230,18 @@ KHG_DEV void khg_inv_wg_body(const KhgInvArgs& a, const KhgInvPlane& pl, int wgl
             // ---- column phase: dequantise, feed the two column pipelines, get natural rows 2(j-2), 2(j-2)+1
             const KhgInvRaw raw = raws[KHG_SLOT];
             const int ke = KHG_INV_KE(j), ko = KHG_INV_KO(j);
-            const int ue = (pairs[KHG_SLOT] - P0) + (ke - klo), uo = (pairs[KHG_SLOT] - P0) + (ko - klo);
+            const int re = ke - klo, ro = ko - klo;
             double c[4];
             if (LEVEL == 1) {
                 c[0] = raw.ll;
-                c[1] = (double)raw.q[1] * sh.dv[0 * KHG_DV_N + ue];  // band 4: (ke, hw + p)
-                c[2] = (double)raw.q[2] * sh.dv[1 * KHG_DV_N + uo];  // band 5: (hh + ko, p)
-                c[3] = (double)raw.q[3] * sh.dv[2 * KHG_DV_N + uo];  // band 6: (hh + ko, hw + p)
+                c[1] = (double)raw.q[1] * sh.dv[0 * KHG_DV_N + uH[KHG_SLOT] + re];  // band 4: (ke, hw + column)
+                c[2] = (double)raw.q[2] * sh.dv[1 * KHG_DV_N + uL[KHG_SLOT] + ro];  // band 5: (hh + ko, column)
+                c[3] = (double)raw.q[3] * sh.dv[2 * KHG_DV_N + uH[KHG_SLOT] + ro];  // band 6: (hh + ko, hw + column)
             } else {
-                c[0] = (double)raw.q[0] * sh.dv[0 * KHG_DV_N + ue];
-                c[1] = (double)raw.q[1] * sh.dv[1 * KHG_DV_N + ue];
-                c[2] = (double)raw.q[2] * sh.dv[2 * KHG_DV_N + uo];
-                c[3] = (double)raw.q[3] * sh.dv[3 * KHG_DV_N + uo];
+                c[0] = (double)raw.q[0] * sh.dv[0 * KHG_DV_N + uL[KHG_SLOT] + re];
+                c[1] = (double)raw.q[1] * sh.dv[1 * KHG_DV_N + uH[KHG_SLOT] + re];
+                c[2] = (double)raw.q[2] * sh.dv[2 * KHG_DV_N + uL[KHG_SLOT] + ro];
+                c[3] = (double)raw.q[3] * sh.dv[3 * KHG_DV_N + uH[KHG_SLOT] + ro];
             }
             // next trip's inputs: in flight during this trip's arithmetic (unconditional: after the last trip the
             // rows are reflected back into the plane and the loads are not used)
@@ -255,11 +265,7 @@ KHG_DEV void khg_inv_wg_body(const KhgInvArgs& a, const KhgInvPlane& pl, int wgl
         {
             KHG_UNROLL
             for (int rr = 0; rr < 2; ++rr) {
-                double dp = X[rr][KHG_SLOT];
-                if (edges[KHG_SLOT] & 2) {
-                    if (flags[KHG_SLOT] & 2) dp = HI[rr][KHG_SLOT];
-                }
-                S1[rr][KHG_SLOT] = LO[rr][KHG_SLOT] + KHG_C1 * (dp + HI[rr][KHG_SLOT]);
+                S1[rr][KHG_SLOT] = LO[rr][KHG_SLOT] + KHG_C1 * (X[rr][KHG_SLOT] + HI[rr][KHG_SLOT]);
             }
         }
         // d1[p] = d[p] + C2 * (s1[p] + s1[p+1])
@@ -268,11 +274,7 @@ KHG_DEV void khg_inv_wg_body(const KhgInvArgs& a, const KhgInvPlane& pl, int wgl
         {
             KHG_UNROLL
             for (int rr = 0; rr < 2; ++rr) {
-                double sn = X[rr][KHG_SLOT];
-                if (edges[KHG_SLOT] & 4) {
-                    if (flags[KHG_SLOT] & 4) sn = S1[rr][KHG_SLOT];
-                }
-                D1[rr][KHG_SLOT] = HI[rr][KHG_SLOT] + KHG_C2 * (S1[rr][KHG_SLOT] + sn);
+                D1[rr][KHG_SLOT] = HI[rr][KHG_SLOT] + KHG_C2 * (S1[rr][KHG_SLOT] + X[rr][KHG_SLOT]);
             }
         }
         // s0[p] = s1[p] + C3 * (d1[p-1] + d1[p])
@@ -281,11 +283,7 @@ KHG_DEV void khg_inv_wg_body(const KhgInvArgs& a, const KhgInvPlane& pl, int wgl
         {
             KHG_UNROLL
             for (int rr = 0; rr < 2; ++rr) {
-                double dp = X[rr][KHG_SLOT];
-                if (edges[KHG_SLOT] & 2) {
-                    if (flags[KHG_SLOT] & 2) dp = D1[rr][KHG_SLOT];
-                }
-                S0[rr][KHG_SLOT] = S1[rr][KHG_SLOT] + KHG_C3 * (dp + D1[rr][KHG_SLOT]);
+                S0[rr][KHG_SLOT] = S1[rr][KHG_SLOT] + KHG_C3 * (X[rr][KHG_SLOT] + D1[rr][KHG_SLOT]);
             }
         }
         // d0[p] = d1[p] + C4 * (s0[p] + s0[p+1]); x[2p] = s0[p], x[2p+1] = d0[p]
@@ -293,17 +291,13 @@ KHG_DEV void khg_inv_wg_body(const KhgInvArgs& a, const KhgInvPlane& pl, int wgl
         KHG_FOR_THREADS(256)
         {
             const int m = j - 2;  // finished row pair
-            if ((flags[KHG_SLOT] & 1) && m >= k0 && m < k1) {
+            if (outl[KHG_SLOT] && m >= k0 && m < k1) {
                 const int pair = pairs[KHG_SLOT];
                 double xe[2], xo[2];
                 KHG_UNROLL
                 for (int rr = 0; rr < 2; ++rr) {
-                    double sn = X[rr][KHG_SLOT];
-                    if (edges[KHG_SLOT] & 4) {
-                        if (flags[KHG_SLOT] & 4) sn = S0[rr][KHG_SLOT];
-                    }
                     xe[rr] = S0[rr][KHG_SLOT];
-                    xo[rr] = D1[rr][KHG_SLOT] + KHG_C4 * (S0[rr][KHG_SLOT] + sn);
+                    xo[rr] = D1[rr][KHG_SLOT] + KHG_C4 * (S0[rr][KHG_SLOT] + X[rr][KHG_SLOT]);
                 }
                 if (RGB) {
                     KHG_UNROLL

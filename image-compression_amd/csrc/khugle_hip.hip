@@ -30,6 +30,17 @@ __global__ __launch_bounds__(256) void khg_table_kernel(KhgTableArgs a)
     khg_table_body(a, (int)blockIdx.x, sh);
 }
 
+// Start of an encode job: the dense histogram (counts 0, first raster indices "absent") and the result block, in
+// one launch (three fills were three dispatches on the job's critical path).
+__global__ __launch_bounds__(256) void khg_job_init_kernel(uint32_t* hist_cnt, uint32_t* hist_first, KhgResult* res)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;  // grid covers 3 * KHG_NBINS / 4 vectors
+    const uint4 zero = {0u, 0u, 0u, 0u}, ones = {~0u, ~0u, ~0u, ~0u};
+    ((uint4*)hist_cnt)[i] = zero;
+    ((uint4*)hist_first)[i] = ones;
+    if (i < sizeof(KhgResult) / 4) ((uint32_t*)res)[i] = 0;
+}
+
 __global__ __launch_bounds__(256) void khg_lens_kernel(KhgEncArgs a)
 {
     __shared__ KhgLensSmem sh;
@@ -348,9 +359,7 @@ static int khg_enqueue_forward_ycbcr(khg_ctx* c, const double* const ycbcr[3], i
                                      double* const coef[3], hipStream_t st)
 {
     KhgWorkspace& ws = c->ws;
-    KHG_HIP(hipMemsetAsync(ws.hist_cnt, 0, 3 * KHG_NBINS * sizeof(uint32_t), st));
-    KHG_HIP(hipMemsetAsync(ws.hist_first, 0xFF, 3 * KHG_NBINS * sizeof(uint32_t), st));
-    KHG_HIP(hipMemsetAsync(ws.res, 0, sizeof(KhgResult), st));
+    hipLaunchKernelGGL(khg_job_init_kernel, dim3(3 * KHG_NBINS / 4 / 256), dim3(256), 0, st, ws.hist_cnt, ws.hist_first, ws.res);
     khg_launch_fwd<KHG_FWD_PLANES1>(khg_fwd_args_planes(ws, rows, cols, lvl, 1, coef, KhgTile{0, 1}, ycbcr), st);
     khg_launch_fwd<KHG_FWD_PLANES2>(khg_fwd_args_planes(ws, rows, cols, lvl, 2, coef), st);
     KHG_HIP(hipGetLastError());
@@ -375,9 +384,7 @@ static int khg_enqueue_forward(khg_ctx* c, const uint8_t* r, const uint8_t* g, c
                                int bgr_stride = 0)
 {
     KhgWorkspace& ws = c->ws;
-    KHG_HIP(hipMemsetAsync(ws.hist_cnt, 0, 3 * KHG_NBINS * sizeof(uint32_t), st));
-    KHG_HIP(hipMemsetAsync(ws.hist_first, 0xFF, 3 * KHG_NBINS * sizeof(uint32_t), st));
-    KHG_HIP(hipMemsetAsync(ws.res, 0, sizeof(KhgResult), st));
+    hipLaunchKernelGGL(khg_job_init_kernel, dim3(3 * KHG_NBINS / 4 / 256), dim3(256), 0, st, ws.hist_cnt, ws.hist_first, ws.res);
     KhgFwdArgs a = khg_fwd_args_rgb(ws, r, g, b, rows, cols, lvl, coef, tile, false, bgr_stride);
     if (c->prof_on) {
         KHG_HIP(hipEventRecord(c->prof_e0, st));
@@ -550,9 +557,7 @@ extern "C" int khg_time_luma_forward_dev(khg_ctx* c, const uint8_t* d_r, const u
     KHG_HIP(hipSetDevice(c->device));
     if ((rc = khg_begin(c, st))) return rc;
     KhgWorkspace& ws = c->ws;
-    KHG_HIP(hipMemsetAsync(ws.hist_cnt, 0, 3 * KHG_NBINS * sizeof(uint32_t), st));
-    KHG_HIP(hipMemsetAsync(ws.hist_first, 0xFF, 3 * KHG_NBINS * sizeof(uint32_t), st));
-    KHG_HIP(hipMemsetAsync(ws.res, 0, sizeof(KhgResult), st));
+    hipLaunchKernelGGL(khg_job_init_kernel, dim3(3 * KHG_NBINS / 4 / 256), dim3(256), 0, st, ws.hist_cnt, ws.hist_first, ws.res);
     KhgFwdArgs a = khg_fwd_args_rgb(ws, d_r, d_g, d_b, rows, cols, lvl, nullptr);
     hipEvent_t e0, e1;
     KHG_HIP(hipEventCreate(&e0));

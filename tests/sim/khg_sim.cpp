@@ -499,10 +499,9 @@ void khgsim_div_const(const double* x, size_t n, double c, double* out_div)
 void khgsim_round_quot(const double* x, const double* d, size_t n, double* out_round, uint8_t* fast)
 {
     for (size_t i = 0; i < n; ++i) {
-        double r;
-        bool ok = khg_round_quot_fast(x[i], 1.0 / d[i], &r);
-        if (!ok) r = round(x[i] / d[i]);
-        out_round[i] = r;
+        int q;
+        const bool ok = khg_quant_try(x[i], 1.0 / d[i], &q);  // the kernels' shortcut; they divide when it declines
+        out_round[i] = ok ? (double)q : round(x[i] / d[i]);
         fast[i] = ok;
     }
 }
