@@ -174,6 +174,7 @@ KHG_DEV void khg_inv_wg_body(const KhgInvArgs& a, const KhgInvPlane& pl, int wgl
         const int p = v0 - 2 + lane;
         outl[KHG_SLOT] = p >= v0 && p < v1;  // a wave beyond the last strip loads and computes without output
         pairs[KHG_SLOT] = p < v0 ? v0 : (p > v0 + KHG_STRIP_PAIRS - 1 ? v0 + KHG_STRIP_PAIRS - 1 : p);
+        if (pairs[KHG_SLOT] > np - 1) pairs[KHG_SLOT] = np - 1;  // it also addresses the chroma sample every lane loads
         colsL[KHG_SLOT] = khg_reflect(2 * p, pl.pw) >> 1;
         colsH[KHG_SLOT] = khg_reflect(2 * p + 1, pl.pw) >> 1;
         const int umax = KHG_WG_STRIPS * KHG_STRIP_PAIRS + 3;  // lanes beyond the plane: any entry of the table

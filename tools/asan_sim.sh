@@ -15,8 +15,8 @@ import simlib as S
 S.SO = "$SO"
 S.build = lambda force=False: None
 import pytest
-sys.exit(pytest.main(["$ROOT/tests/test_sim_kernels.py", "$ROOT/tests/test_tiled.py", "-x", "-q", "-k", "not gloo",
+sys.exit(pytest.main(["$ROOT/tests/test_sim_kernels.py", "$ROOT/tests/test_tiled.py", "-x", "-q", "-k", "not gloo and not every_rank",
                       "-p", "no:cacheprovider"]))
 PY
-ASAN_OPTIONS=detect_leaks=0 LD_PRELOAD=$(g++ -print-file-name=libasan.so) python /tmp/run_asan_suite.py
-KHG_SIM_SO=$SO ASAN_OPTIONS=detect_leaks=0 LD_PRELOAD=$(g++ -print-file-name=libasan.so) python "$ROOT/tools/fuzz_sim.py" 1 300
+ASAN_OPTIONS=detect_leaks=0 LD_PRELOAD=$(g++ -print-file-name=libasan.so)${LD_PRELOAD:+:$LD_PRELOAD} python /tmp/run_asan_suite.py
+KHG_SIM_SO=$SO ASAN_OPTIONS=detect_leaks=0 LD_PRELOAD=$(g++ -print-file-name=libasan.so)${LD_PRELOAD:+:$LD_PRELOAD} python "$ROOT/tools/fuzz_sim.py" 1 300
