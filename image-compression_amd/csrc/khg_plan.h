@@ -103,44 +103,6 @@ static inline void khg_workspace_sizes(int rows, int cols, KhgWorkspaceSizes* s)
     s->chunk_off = nch * sizeof(uint64_t);
 }
 
-// Grid of one forward-transform launch over a ph x pw plane.
-struct KhgFwdGrid {
-    int nstrip, nseg, seg_rows;
-};
-// Splits ph rows into equal even-height segments for nstrip column strips.  Workgroups run in rounds of
-// `slots` (resident workgroups on the chip); a workgroup walks its rows plus `halo` warm-up rows in whole batches
-// of 16 rows (KHG_BATCH; 8 row pairs in the inverse transform), so the segment count is the one that minimises
-// rounds x batches -- the launch's critical path -- and, among those, the batches summed over all workgroups (the
-// work other launches cannot use), with 32 <= rows <= max_rows.
-static inline KhgFwdGrid khg_strip_grid(int ph, int nstrip, int slots, int halo, int max_rows)
-{
-    KhgFwdGrid g;
-    g.nstrip = nstrip;
-    int lo = (ph + max_rows - 1) / max_rows, hi = ph / 32;
-    if (lo < 1) lo = 1;
-    if (hi < lo) hi = lo;
-    long best = -1, best_work = -1;
-    for (int n = lo; n <= hi; ++n) {
-        int seg = ((ph + n - 1) / n + 1) & ~1;
-        if (seg > max_rows) continue;
-        int nseg = (ph + seg - 1) / seg;
-        long rounds = ((long)nstrip * nseg + slots - 1) / slots;
-        long batches = (seg + halo + 15) / 16;
-        long cost = rounds * batches, work = (long)nstrip * nseg * batches;
-        if (best < 0 || cost < best || (cost == best && work < best_work)) {
-            best = cost;
-            best_work = work;
-            g.seg_rows = seg;
-            g.nseg = nseg;
-        }
-    }
-    if (best < 0) {  // ph below one minimal segment
-        g.seg_rows = (ph + 1) & ~1;
-        g.nseg = 1;
-    }
-    return g;
-}
-
 // One tile of a row-tiled image: rank t of n owns image rows [rows*t/n, rows*(t+1)/n), rows/n a multiple of 8
 // so luma and chroma bands line up at both levels.  {0, 1} is the whole image.
 struct KhgTile {

@@ -483,12 +483,19 @@ void khgsim_synth(uint8_t* r, uint8_t* g, uint8_t* b, int rows, int cols, uint32
 // Arithmetic shortcuts against the operations they replace: out_div[i] = khg_div_const(x[i], c, 1/c),
 // out_round[i] = the quantiser's rounding of x[i] / d[i]; fast[i] = 1 when no division was needed.
 // host-side planning: segment height and count chosen for a transform of ph rows
-void khgsim_strip_grid(int ph, int nstrip, int slots, int halo, int max_rows, int* seg_rows, int* nseg)
+// The grid planner of the transform launches: groups of (pw, span, weight) -> per group seg_rows, nseg, nstrip_wg,
+// wg0 (4 ints each, in `out`); returns the workgroup count.
+int khgsim_plan_groups(const int* groups, int ngroup, int slots, int* out)
 {
-    KhgFwdGrid g = khg_strip_grid(ph, nstrip, slots, halo, max_rows);
-    *seg_rows = g.seg_rows;
-    *nseg = g.nseg;
+    KhgGridGroup g[3];
+    for (int i = 0; i < ngroup; ++i) { g[i].pw = groups[3 * i]; g[i].span = groups[3 * i + 1]; g[i].weight = groups[3 * i + 2]; }
+    const int n = khg_plan_groups(g, ngroup, slots);
+    for (int i = 0; i < ngroup; ++i) { out[4 * i] = g[i].seg_rows; out[4 * i + 1] = g[i].nseg; out[4 * i + 2] = g[i].nstrip_wg; out[4 * i + 3] = g[i].wg0; }
+    return n;
 }
+
+// Rows of segment `seg` (khg_segment_rows).
+void khgsim_segment_rows(int begin, int end, int nseg, int seg, int* r0, int* r1) { khg_segment_rows(begin, end, nseg, seg, r0, r1); }
 
 void khgsim_div_const(const double* x, size_t n, double c, double* out_div)
 {

@@ -147,14 +147,24 @@ def synth(rows, cols, seed, index):
     return out
 
 
-def strip_grid(ph, nstrip, slots, halo, max_rows):
-    """(seg_rows, nseg) the host planner picks for a transform of ph rows."""
-    seg = C.c_int(); nseg = C.c_int()
+def plan_groups(groups, slots):
+    """groups: [(pw, span, weight)] -> (workgroups, [(seg_rows, nseg, nstrip_wg, wg0)]) from khg_plan_groups."""
     L = lib()
-    L.khgsim_strip_grid.argtypes = [C.c_int] * 5 + [C.POINTER(C.c_int)] * 2
-    L.khgsim_strip_grid.restype = None
-    L.khgsim_strip_grid(ph, nstrip, slots, halo, max_rows, C.byref(seg), C.byref(nseg))
-    return seg.value, nseg.value
+    n = len(groups)
+    gin = (C.c_int * (3 * n))(*[v for g in groups for v in g])
+    out = (C.c_int * (4 * n))()
+    L.khgsim_plan_groups.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    wgs = L.khgsim_plan_groups(gin, n, slots, out)
+    return wgs, [tuple(out[4 * i:4 * i + 4]) for i in range(n)]
+
+
+def segment_rows(begin, end, nseg, seg):
+    r0, r1 = C.c_int(0), C.c_int(0)
+    L = lib()
+    L.khgsim_segment_rows.argtypes = [C.c_int] * 4 + [C.POINTER(C.c_int)] * 2
+    L.khgsim_segment_rows.restype = None
+    L.khgsim_segment_rows(begin, end, nseg, seg, C.byref(r0), C.byref(r1))
+    return r0.value, r1.value
 
 
 def div_const(x, c):

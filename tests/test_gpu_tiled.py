@@ -81,6 +81,39 @@ def test_tile_entry_points_reject_bad_geometry(codec):
                                                frame[2].data_ptr(), 72, 64, 1, 0, 2, None), "tile_forward")
 
 
+def test_split_decode_steps_are_checked(codec):
+    """The split-decode entry points refuse to run out of order or with bad arguments instead of touching memory."""
+    import ctypes as C
+    from khugle_amd.lib import ERR_ARG, ERR_DIMS, ERR_FORMAT
+    L = codec.L
+    frame = codec.synth_dev(64, 64, 1, 0)
+    comp = codec.encode(frame.cpu().numpy(), 1)
+    d_comp = torch.from_numpy(np.frombuffer(comp + b"\0" * 8, np.uint8).copy()).cuda()
+    out = torch.empty((3, 32, 64), dtype=torch.uint8, device="cuda")
+    bounds = (C.c_uint32 * 9)()
+    # nothing mapped yet
+    assert L.khg_tile_blk_words(codec._ctx) == 0
+    assert L.khg_tile_decode_write_dev(codec._ctx, bounds, None) == ERR_ARG
+    assert L.khg_tile_decode_inverse_dev(codec._ctx, out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), None) == ERR_ARG
+    assert L.khg_tile_decode_map_dev(codec._ctx, d_comp.data_ptr(), 40, 64, 64, 0, 2, None) == ERR_FORMAT
+    assert L.khg_tile_decode_map_dev(codec._ctx, d_comp.data_ptr(), len(comp), 72, 64, 0, 2, None) == ERR_DIMS
+    r = (C.c_uint32 * 8)()
+    assert L.khg_tile_need_ranges(64, 64, 2, 2, 0, r) == ERR_DIMS and L.khg_tile_need_ranges(64, 64, 0, 2, 3, r) == ERR_DIMS
+    # mapped, not written: symbols cannot be moved and the inverse cannot run yet
+    assert L.khg_tile_decode_map_dev(codec._ctx, d_comp.data_ptr(), len(comp), 64, 64, 0, 2, None) == 0
+    assert L.khg_tile_blk_words(codec._ctx) > 0
+    buf = torch.empty(16, dtype=torch.int16, device="cuda")
+    assert L.khg_tile_sym_get(codec._ctx, 0, 0, 16, buf.data_ptr(), None) == ERR_ARG
+    assert L.khg_tile_decode_inverse_dev(codec._ctx, out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), None) == ERR_ARG
+    assert L.khg_tile_decode_write_dev(codec._ctx, bounds, None) == 0
+    assert L.khg_tile_sym_get(codec._ctx, 0, 64 * 64 - 8, 16, buf.data_ptr(), None) == ERR_ARG  # beyond the plane
+    assert L.khg_tile_sym_get(codec._ctx, 3, 0, 16, buf.data_ptr(), None) == ERR_ARG
+    assert L.khg_tile_sym_get(codec._ctx, 0, 0, 16, buf.data_ptr(), None) == 0
+    assert L.khg_tile_decode_inverse_dev(codec._ctx, out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), None) == 0
+    codec.last_status()  # the job is fetched (rank 0 of 2 decoded half the stream only: its status is its own)
+    assert L.khg_tile_decode_inverse_dev(codec._ctx, out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), None) == ERR_ARG
+
+
 class _HostStaged:
     """Collectives of khugle_amd.tiled for a gloo group: device tensors go through host memory."""
 

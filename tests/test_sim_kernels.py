@@ -100,25 +100,36 @@ def test_decode_codes_beyond_32_bits():
     assert np.array_equal(out, O.decode(comp))
 
 
-def test_strip_grid_plans_whole_batches():
-    """The planner covers every row with even segments inside the limits, and counts cost in whole 16-row batches:
-    no other segment height has a shorter critical path (rounds x batches), nor the same with fewer batches in all."""
-    for ph in (8, 40, 264, 1080, 2160, 4320, 5760):
-        for nstrip, slots, max_rows in ((1, 1024, 128), (8, 768, 128), (30, 1024, 128), (32, 1280, 512)):
-            seg, nseg = S.strip_grid(ph, nstrip, slots, 8, max_rows)
-            assert seg % 2 == 0 and seg * nseg >= ph and seg * (nseg - 1) < ph
-            if ph >= 32:
-                assert 32 <= seg <= max_rows or nseg == 1
-
-                def cost(s_):
-                    n_ = -(-ph // s_)
-                    rounds, batches = -(-nstrip * n_ // slots), -(-(s_ + 8) // 16)
-                    return rounds * batches, nstrip * n_ * batches
-                best = cost(seg)
-                for n_ in range(max(1, -(-ph // max_rows)), ph // 32 + 1):
-                    s_ = (-(-ph // n_) + 1) & ~1
-                    if s_ <= max_rows:
-                        assert cost(s_) >= best, (ph, nstrip, slots, seg, s_)
+def test_grid_planner_balances_the_workgroups_of_a_launch():
+    """khg_plan_groups: every group's rows are covered by even segments of 16..120 rows that differ by at most one
+    row pair; all workgroups of the launch fit the chip at once unless every group is at its tallest already; and
+    the groups' workgroups cost about the same ((rows + 8 warm-up rows) x weight)."""
+    cases = [([(7680, 4320, 4), (3840, 2160, 9)], 1024),     # 8K level 1: luma, Cb + Cr
+             ([(3840, 2160, 1), (1920, 1080, 1), (1920, 1080, 1)], 1024),  # 8K level 2
+             ([(5760, 5760, 4), (2880, 2880, 9)], 1024), ([(8, 8, 4), (4, 4, 9)], 1024),
+             ([(520, 264, 1)], 1024), ([(32768, 4096 + 16, 4), (16384, 2048 + 8, 9)], 1024),  # a tile of 32768^2
+             ([(7680, 4320, 4), (3840, 2160, 9)], 512)]
+    for groups, slots in cases:
+        wgs, plan = S.plan_groups(groups, slots)
+        total, costs, all_max = 0, [], True
+        for (pw, span, weight), (seg_rows, nseg, nstrip_wg, wg0) in zip(groups, plan):
+            assert wg0 == total
+            assert nstrip_wg == -(-(-(-(pw // 2) // 60)) // 4)
+            total += nstrip_wg * nseg
+            assert seg_rows % 2 == 0 and seg_rows <= 120
+            rows = [S.segment_rows(0, span, nseg, i) for i in range(nseg)]
+            assert rows[0][0] == 0 and rows[-1][1] == span
+            assert all(a[1] == b[0] for a, b in zip(rows, rows[1:]))
+            heights = [r1 - r0 for r0, r1 in rows]
+            assert all(h % 2 == 0 and 0 < h <= seg_rows for h in heights) and max(heights) - min(heights) <= 2
+            if span > 16:
+                assert max(heights) >= 16 or nseg == 1
+            costs.append((max(heights) + 8) * weight)
+            all_max = all_max and nseg == -(-span // 120)  # as few segments as the 120-row limit allows
+        assert total == wgs
+        assert wgs <= slots or all_max
+        if len(costs) > 1 and not all_max and min(c for c in costs) > 24 * 9:
+            assert max(costs) <= 1.25 * min(costs), (groups, plan, costs)
 
 
 def test_output_capacity_is_checked():
