@@ -47,6 +47,8 @@ static inline uint32_t khg_bswap32(uint32_t v) { return __builtin_bswap32(v); }
 static inline double khg_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 static inline unsigned long long khg_clock(void) { return 0; }
 static inline void khg_atomic_max64(unsigned long long* p, unsigned long long v) { if (v > *p) *p = v; }
+static inline uint64_t khg_chain_load(const uint64_t* p) { return *p; }
+static inline void khg_chain_store(uint64_t* p, uint64_t v) { *p = v; }
 #else
 #include <hip/hip_runtime.h>
 #define KHG_DEV __device__ __forceinline__
@@ -107,6 +109,10 @@ __device__ __forceinline__ uint32_t khg_bswap32(uint32_t v) { return __builtin_b
 __device__ __forceinline__ double khg_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }  // explicit: not subject to -ffp-contract
 __device__ __forceinline__ unsigned long long khg_clock(void) { return (unsigned long long)wall_clock64(); }  // constant 100 MHz, chip-wide
 __device__ __forceinline__ void khg_atomic_max64(unsigned long long* p, unsigned long long v) { atomicMax(p, v); }
+// State words that workgroups of one launch publish to each other (each word is self-contained: no other memory is
+// ordered by them).
+__device__ __forceinline__ uint64_t khg_chain_load(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void khg_chain_store(uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 #endif
 
 // ---------------------------------------------------------------- constants

@@ -10,6 +10,8 @@
 #pragma once
 #include "khg_common.h"
 
+enum { KHG_CHAIN_HEAD = 2 };  // words of KhgEncArgs::chain before the per-chunk state ([0]: next ticket)
+
 enum {
     KHG_TREE_LDS_K = 4096,  // tables up to this size build their tree in LDS
     KHG_TABLE_LDS_WORDS = 2 * KHG_NBINS  // 128 KiB: entry list (first, bin), later heap + node arrays
@@ -303,6 +305,8 @@ struct KhgEncArgs {
     const uint64_t* codetab;   // [3][KHG_NBINS]
     uint32_t* chunk_bits;      // [nchunks]
     uint64_t* chunk_off;       // [nchunks] bit offset in the output file
+    uint64_t* chain;           // state of the single-pass packer (khg_packscan_body)
+    uint32_t chain_entries;    // its entries: superchunks of the three planes + 3 pad entries
     const int32_t* tab_cnt;    // [3][KHG_NBINS]
     const int32_t* tab_sym;
     const int32_t* tab_k;      // [3]
@@ -600,13 +604,13 @@ struct KhgPackSmem {
     uint64_t hot[KHG_HOT_SYMS];  // see KHG_HOT_SYMS
 };
 
-// Table entry of symbol v: (length << 56) | code.
-KHG_DEV uint64_t khg_pack_code(const KhgPackSmem& sh, const uint64_t* ctab, int v)
+// Table entry of symbol v: (length << 56) | code.  hot: the workgroup's LDS copy of the entries of -128 .. 127.
+KHG_DEV uint64_t khg_pack_code_lds(const uint64_t* hot, const uint64_t* ctab, int v)
 {
     // the LDS entry is fetched unconditionally (index wrapped) and replaced on the rare path: a select between
     // an LDS and a global address would turn both into one flat load
     const uint32_t h = (uint32_t)(v + KHG_HOT_SYMS / 2);
-    uint64_t c = sh.hot[h & (KHG_HOT_SYMS - 1)];
+    uint64_t c = hot[h & (KHG_HOT_SYMS - 1)];
     if (h >= (uint32_t)KHG_HOT_SYMS) {
         KHG_OPAQUE(c);  // the LDS load stays a load of its own
         c = ctab[v + KHG_SYM_BIAS];
@@ -668,7 +672,7 @@ KHG_DEV void khg_pack_body(const KhgEncArgs& a, uint32_t chunk, KhgPackSmem& sh)
         KHG_UNROLL
         for (int i = 0; i < 8; ++i) {
             if (i < nv) {
-                const uint64_t c = khg_pack_code(sh, ctab, v[i]);
+                const uint64_t c = khg_pack_code_lds(sh.hot, ctab, v[i]);
                 const uint32_t len = (uint32_t)(c >> 56);
                 ac = (ac << len) | (c & 0x00FFFFFFFFFFFFFFull);  // meaningful while tb <= 64 (len <= 56)
                 tb += len;
@@ -692,7 +696,7 @@ KHG_DEV void khg_pack_body(const KhgEncArgs& a, uint32_t chunk, KhgPackSmem& sh)
             KHG_UNROLL
             for (int i = 0; i < 8; ++i) {  // constant indices: the symbols stay in registers
                 if (i < nv) {
-                    const uint64_t c = khg_pack_code(sh, ctab, v[i]);
+                    const uint64_t c = khg_pack_code_lds(sh.hot, ctab, v[i]);
                     const uint32_t len = (uint32_t)(c >> 56);
                     khg_pack_put(sh.words, pos, c & 0x00FFFFFFFFFFFFFFull, len);
                     pos += len;
@@ -708,6 +712,419 @@ KHG_DEV void khg_pack_body(const KhgEncArgs& a, uint32_t chunk, KhgPackSmem& sh)
             uint32_t v = khg_bswap32(sh.words[i]);  // first stream bit = MSB of the first byte
             if (i == 0 || i == nw - 1) khg_atomic_or(&out32[i], v);
             else out32[i] = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- single-pass packer
+//
+// khg_lens_body + khg_scan_body + khg_pack_body in one pass over the symbols (whole images on one GPU; row-tiled
+// images keep the three steps, because the chunk bit counts travel between the ranks).  Where a chunk's bits go
+// depends on the lengths of all chunks before it; instead of a first pass that only measures, the workgroups of
+// the launch tell each other (decoupled look-back, two levels):
+//   * the launch's entries are, in order: Y superchunks (KHG_SUPER chunks = 16384 symbols), pad, Cb superchunks,
+//     pad, Cr superchunks, pad ("pad" = the zero bits that fill a plane's stream up to a byte, Compress.h:310-328).
+//     A workgroup takes the next entry when it STARTS (a ticket), so every entry before its own belongs to a
+//     workgroup that is already running;
+//   * a workgroup first turns its symbols into per-thread code strings held in registers, which gives the entry's
+//     bit count, and publishes AGG = (bit count, the entry's last <= 32 bits).  The last entry of every group of 64
+//     also publishes the group's bit count (GAGG);
+//   * wave 0 then finds the entry's start: the bit counts of the entries before it in its group (one load per
+//     lane) plus the end of the previous group -- its published end (GPRE), or the nearest published group end plus
+//     the group counts in between.  It publishes its own end (PRE; a group's last entry also GPRE).  A pad entry
+//     can only publish once the plane before it is complete; that is the one real dependency of the format;
+//   * the workgroup then assembles chunk after chunk in LDS and writes the 32-bit words each one COMPLETES: the
+//     first word begins with the last (start mod 32) bits of the stream before it -- the previous chunk's, or for
+//     the entry's first chunk the tail in its predecessors' AGG words; the entry's own unfinished last word is left
+//     to its successor.  No word is written twice, so nothing has to be zeroed or OR-merged.
+// Every wait is bounded: a workgroup that gives up flags the job (KHG_ERR_HIP) and ends, so the grid drains.
+
+enum {
+    KHG_SUPER = 8,               // chunks per entry
+    KHG_CHAIN_GROUP = 64,        // entries per group
+    KHG_CHAIN_SPINS = 1 << 17    // polls (about a microsecond each) before a workgroup gives up
+};
+#define KHG_CHAIN_VALID (1ull << 63)
+
+KHG_HOST_DEV uint32_t khg_chain_plane_entries(uint32_t plane_chunks) { return (plane_chunks + KHG_SUPER - 1) / KHG_SUPER; }
+
+KHG_DEV uint64_t* khg_chain_agg(const KhgEncArgs& a, uint32_t i) { return a.chain + KHG_CHAIN_HEAD + 2 * (size_t)i; }
+KHG_DEV uint64_t* khg_chain_pre(const KhgEncArgs& a, uint32_t i) { return a.chain + KHG_CHAIN_HEAD + 2 * (size_t)i + 1; }
+KHG_DEV uint64_t* khg_chain_gagg(const KhgEncArgs& a, uint32_t g) { return a.chain + KHG_CHAIN_HEAD + 2 * ((size_t)a.chain_entries + g); }
+KHG_DEV uint64_t* khg_chain_gpre(const KhgEncArgs& a, uint32_t g) { return a.chain + KHG_CHAIN_HEAD + 2 * ((size_t)a.chain_entries + g) + 1; }
+
+// Entry t of the launch: plane, whether it is the plane's pad entry, and otherwise its symbols.
+struct KhgChainEntry {
+    int plane;
+    bool pad;
+    uint32_t sym0, sym1;  // raster range of the entry's symbols
+    uint32_t plane_entries;
+};
+KHG_DEV KhgChainEntry khg_chain_entry(const KhgEncArgs& a, uint32_t t)
+{
+    KhgChainEntry e = {2, true, 0, 0, 0};
+    for (int p = 0; p < 3; ++p) {
+        const uint32_t ne = khg_chain_plane_entries((p < 2 ? a.chunk0[p + 1] : a.nchunks) - a.chunk0[p]);
+        e.plane = p;
+        e.plane_entries = ne;
+        if (t < ne) {
+            e.pad = false;
+            e.sym0 = t * (uint32_t)(KHG_SUPER * KHG_CHUNK);
+            e.sym1 = a.n[p] - e.sym0 < (uint32_t)(KHG_SUPER * KHG_CHUNK) ? a.n[p] : e.sym0 + (uint32_t)(KHG_SUPER * KHG_CHUNK);
+            return e;
+        }
+        t -= ne;
+        if (t == 0) return e;
+        t -= 1;
+    }
+    return e;
+}
+
+// Waits (bounded) for a published word.  Returns 0 if it never came.
+KHG_DEV uint64_t khg_chain_wait(const uint64_t* p)
+{
+    uint64_t v = khg_chain_load(p);
+#ifndef KHG_SIM
+    for (int spin = 0; !(v & KHG_CHAIN_VALID) && spin < KHG_CHAIN_SPINS; ++spin) {
+        __builtin_amdgcn_s_sleep(2);
+        v = khg_chain_load(p);
+    }
+#endif
+    return (v & KHG_CHAIN_VALID) ? v : 0;
+}
+
+KHG_DEV uint32_t khg_agg_bits(uint64_t v) { return (uint32_t)((v >> 32) & 0x7FFFFFFFu); }
+
+// The last (up to 32) bits of the stream before entry c, right-aligned (fewer than 32 exist only at the very start
+// of the file's streams, which is word-aligned, so they are never needed there).  One thread.
+KHG_DEV uint32_t khg_chain_tail_before(const KhgEncArgs& a, uint32_t c)
+{
+    uint32_t bits = 0, have = 0;
+    for (uint32_t i = c; i-- > 0 && have < 32;) {
+        const uint64_t v = khg_chain_wait(khg_chain_agg(a, i));
+        if (!v) {
+            khg_set_status(&a.res->status, -6);
+            break;
+        }
+        const uint32_t b = khg_agg_bits(v), tail = (uint32_t)v;
+        const uint32_t take = b < 32 - have ? b : 32 - have;  // the entry's last `take` bits (its tail holds min(32, b))
+        if (take) {
+            const uint32_t part = take >= 32 ? tail : (tail & ((1u << take) - 1));
+            bits |= part << have;
+            have += take;
+        }
+    }
+    return bits;
+}
+
+// ---- wave collectives of the look-back: `lane` 0..63 of wave 0 call them together (the simulator runs the lanes one
+// after another, so there they are plain loops executed by lane 0 and no-ops for the others).
+// Sum of the bit counts of entries [first, first + n) (n <= 64); 0 valid flag -> failure reported through *ok.
+KHG_DEV uint64_t khg_chain_sum_window(const uint64_t* words, uint32_t n, int lane, bool* ok)
+{
+#ifdef KHG_SIM
+    uint64_t s = 0;
+    if (lane == 0)
+        for (uint32_t l = 0; l < n; ++l) {
+            const uint64_t v = khg_chain_wait(words + 2 * (size_t)l);
+            if (!v) *ok = false;
+            s += khg_agg_bits(v);
+        }
+    return s;
+#else
+    uint64_t v = KHG_CHAIN_VALID;
+    if ((uint32_t)lane < n) v = khg_chain_wait(words + 2 * (size_t)lane);
+    if (__any(v == 0)) *ok = false;
+    unsigned long long part = (uint32_t)lane < n ? khg_agg_bits(v) : 0;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
+    return part;
+#endif
+}
+
+// End position of the stream before group g (g >= 1): the nearest published group end plus the bit counts of the
+// groups in between.
+KHG_DEV uint64_t khg_chain_group_start(const KhgEncArgs& a, uint32_t g, int lane, bool* ok)
+{
+    const uint64_t origin = 36 * 8;  // the streams start behind the 36-byte header (Writer.h:9-23)
+#ifdef KHG_SIM
+    (void)lane;
+    const uint64_t v = khg_chain_wait(khg_chain_gpre(a, g - 1));  // groups complete one after another
+    if (!v) *ok = false;
+    (void)origin;
+    return v & ~KHG_CHAIN_VALID;
+#else
+    uint64_t sum = 0;
+    int64_t hi = (int64_t)g - 1;
+    for (;;) {
+        if (hi < 0) return origin + sum;
+        const int64_t i = hi - lane;
+        uint64_t gagg = KHG_CHAIN_VALID, gpre = 0;
+        if (i >= 0) {
+            gpre = khg_chain_load(khg_chain_gpre(a, (uint32_t)i));
+            if (!(gpre & KHG_CHAIN_VALID)) gagg = khg_chain_wait(khg_chain_gagg(a, (uint32_t)i));
+        }
+        if (__any(gagg == 0)) {
+            *ok = false;
+            return origin;
+        }
+        const unsigned long long known = __ballot(i >= 0 && (gpre & KHG_CHAIN_VALID));
+        const int first = known ? __builtin_ctzll(known) : 64;  // nearest group whose end is known
+        unsigned long long part = (i >= 0 && lane < first) ? (gagg & ~KHG_CHAIN_VALID) : 0;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
+        sum += part;
+        if (known) return __shfl((unsigned long long)(gpre & ~KHG_CHAIN_VALID), first, 64) + sum;
+        hi -= 64;
+    }
+#endif
+}
+
+// The entry's last (up to 32) bits, from its last (up to 64) symbols: every code has at least one bit, so 32
+// symbols always suffice.  Wave 0.
+KHG_DEV uint32_t khg_entry_tail32(const KhgEncArgs& a, int p, const uint64_t* hot, uint32_t sym0, uint32_t sym1, int lane)
+{
+    const uint64_t* ctab = a.codetab + (size_t)p * KHG_NBINS;
+    const uint32_t n = sym1 - sym0 < 64u ? sym1 - sym0 : 64u;
+#ifdef KHG_SIM
+    uint32_t tail = 0, pos = 0;
+    if (lane == 0)
+        for (uint32_t i = 0; i < n && pos < 32; ++i) {  // from the last symbol backwards
+            const uint64_t c = khg_pack_code_lds(hot, ctab, a.sym[p][sym1 - 1 - i]);
+            const uint32_t len = (uint32_t)(c >> 56);
+            tail |= (uint32_t)((c & 0x00FFFFFFFFFFFFFFull) << pos);
+            pos += len;
+        }
+    return tail;
+#else
+    // lane l takes the symbol l places before the last one; pos = bits of the symbols behind it
+    uint32_t len = 0;
+    uint64_t code = 0;
+    if ((uint32_t)lane < n) {
+        const uint64_t c = khg_pack_code_lds(hot, ctab, a.sym[p][sym1 - 1 - (uint32_t)lane]);
+        len = (uint32_t)(c >> 56);
+        code = c & 0x00FFFFFFFFFFFFFFull;
+    }
+    const uint32_t pos = khg_wave_incl_scan(len) - len;
+    uint32_t part = pos < 32 ? (uint32_t)(code << pos) : 0u;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) part |= (uint32_t)__shfl_xor((int)part, d, 64);
+    return part;
+#endif
+}
+
+struct KhgPackScanSmem {
+    uint32_t words[KHG_PACK_WORDS];
+    uint32_t wave[KHG_SUPER][4];
+    uint64_t hot[KHG_HOT_SYMS];
+    uint64_t start;      // absolute bit position of the entry
+    uint32_t carry[2];   // the 32 stream bits before the chunk being written (ping-pong between chunks)
+    uint32_t nbits;      // a pad entry: its pad bits
+};
+
+// One entry of the chain per workgroup (`t` = its ticket; the GPU kernel draws it, the simulator passes 0, 1, 2 ...).
+KHG_DEV void khg_packscan_body(const KhgEncArgs& a, uint32_t t, KhgPackScanSmem& sh)
+{
+    const KhgChainEntry en = khg_chain_entry(a, t);
+    const int p = en.plane;
+    const uint64_t* ctab = a.codetab + (size_t)p * KHG_NBINS;
+    const uint32_t group = t / KHG_CHAIN_GROUP, in_group = t % KHG_CHAIN_GROUP;
+    const bool closes_group = in_group == KHG_CHAIN_GROUP - 1 || t == a.chain_entries - 1;
+
+    uint64_t acc[KHG_SUPER][KHG_NSLOT(256)];
+    uint32_t tbs[KHG_SUPER][KHG_NSLOT(256)], excl[KHG_SUPER][KHG_NSLOT(256)];
+    KHG_FOR_THREADS(256) { sh.hot[tid] = ctab[KHG_SYM_BIAS - KHG_HOT_SYMS / 2 + tid]; }
+    KHG_BARRIER();
+    // every thread's eight symbols of every chunk as one code string (nearly always 64 bits or fewer)
+    KHG_FOR_THREADS(256)
+    {
+        KHG_UNROLL
+        for (int j = 0; j < KHG_SUPER; ++j) {
+            int16_t v[8];
+            const uint32_t s0 = en.sym0 + (uint32_t)j * KHG_CHUNK + (uint32_t)tid * 8;
+            const int nv = (en.pad || s0 >= en.sym1) ? 0 : khg_load8(a.sym[p], s0, en.sym1, v);
+            uint32_t tb = 0;
+            uint64_t ac = 0;
+            KHG_UNROLL
+            for (int i = 0; i < 8; ++i) {
+                if (i < nv) {
+                    const uint64_t c = khg_pack_code_lds(sh.hot, ctab, v[i]);
+                    const uint32_t len = (uint32_t)(c >> 56);
+                    ac = (ac << len) | (c & 0x00FFFFFFFFFFFFFFull);  // meaningful while tb <= 64 (len <= 56)
+                    tb += len;
+                }
+            }
+            acc[j][KHG_SLOT] = ac;
+            tbs[j][KHG_SLOT] = tb;
+        }
+    }
+    uint32_t tot[KHG_SUPER], sub_base[KHG_SUPER], total = 0;  // bits of each chunk, their offsets in the entry
+    for (int j = 0; j < KHG_SUPER; ++j) {
+        KHG_WG_EXCL_SCAN(excl[j], tbs[j], sh.wave[j], tot[j])
+        sub_base[j] = total;
+        total += tot[j];
+    }
+    // publish the entry's bit count and tail, find its place, publish its end
+    KHG_FOR_THREADS(256)
+    {
+        if (tid < 64) {
+            bool ok = true;
+            if (!en.pad) {
+                const uint32_t tail = khg_entry_tail32(a, p, sh.hot, en.sym0, en.sym1, tid);
+                if (tid == 0) khg_chain_store(khg_chain_agg(a, t), KHG_CHAIN_VALID | ((uint64_t)total << 32) | tail);
+                if (closes_group) {  // the group's bit count, for look-backs that find no published group end nearby
+                    const uint64_t gsum = khg_chain_sum_window(khg_chain_agg(a, group * KHG_CHAIN_GROUP), in_group + 1, tid, &ok);
+                    if (tid == 0) khg_chain_store(khg_chain_gagg(a, group), KHG_CHAIN_VALID | gsum);
+                }
+            }
+            // entries before this one in its group, then everything before the group
+            uint64_t start = khg_chain_sum_window(khg_chain_agg(a, group * KHG_CHAIN_GROUP), in_group, tid, &ok);
+            start += group ? khg_chain_group_start(a, group, tid, &ok) : 36 * 8;
+            uint32_t bits = total;
+            if (en.pad) bits = (uint32_t)((8 - (start & 7)) & 7);  // Compress.h:310-328: '0' bits up to a byte
+            if (tid == 0) {
+                if (!ok) khg_set_status(&a.res->status, -6);
+                if (en.pad) {  // the plane's lengths for the header
+                    uint64_t plane_start = 36 * 8;
+                    if (p > 0) plane_start = khg_chain_wait(khg_chain_pre(a, t - 1 - en.plane_entries)) & ~KHG_CHAIN_VALID;
+                    const uint64_t padded = start + bits - plane_start;
+                    a.res->bits[p] = padded >= ((uint64_t)1 << 31) ? -1 : (int32_t)padded;  // checked by khg_meta_body
+                    a.res->pads[p] = (int32_t)bits;
+                    khg_chain_store(khg_chain_agg(a, t), KHG_CHAIN_VALID | ((uint64_t)bits << 32));
+                }
+                khg_chain_store(khg_chain_pre(a, t), KHG_CHAIN_VALID | (start + bits));
+                if (closes_group) khg_chain_store(khg_chain_gpre(a, group), KHG_CHAIN_VALID | (start + bits));
+                sh.start = start;
+                sh.carry[0] = (start & 31) ? khg_chain_tail_before(a, t) : 0;
+                sh.nbits = bits;
+            }
+            if (closes_group && en.pad) {  // a pad entry's own count is only known now
+                const uint64_t gsum = khg_chain_sum_window(khg_chain_agg(a, group * KHG_CHAIN_GROUP), in_group + 1, tid, &ok);
+                if (tid == 0) khg_chain_store(khg_chain_gagg(a, group), KHG_CHAIN_VALID | gsum);
+            }
+        }
+    }
+    KHG_BARRIER();
+    if (en.pad) tot[0] = sh.nbits;
+    const bool last = en.pad && p == 2;  // the file's streams end here: the unfinished word is flushed too
+    const int nsub = en.pad ? 1 : KHG_SUPER;
+    for (int j = 0; j < nsub; ++j) {
+        const uint32_t bits = tot[j];
+        const uint64_t start = sh.start + sub_base[j];
+        const uint32_t r = (uint32_t)(start & 31);
+        KHG_FOR_THREADS(256)
+        {
+            // the words the chunk's bits reach, and one more (the funnel shift below reads a word past the last bit)
+            for (uint32_t i = (uint32_t)tid; i < ((bits + 31) >> 5) + 2; i += 256) sh.words[i] = 0;
+        }
+        KHG_BARRIER();
+        KHG_FOR_THREADS(256)
+        {
+            if (!en.pad) {
+                uint32_t pos = excl[j][KHG_SLOT];  // the chunk's first bit is the top bit of words[0]
+                const uint32_t tb = tbs[j][KHG_SLOT];
+                if (tb <= 64) {
+                    khg_pack_put(sh.words, pos, acc[j][KHG_SLOT], tb);
+                } else {  // long codes: one at a time, from the symbols again
+                    int16_t v[8];
+                    const int nv = khg_load8(a.sym[p], en.sym0 + (uint32_t)j * KHG_CHUNK + (uint32_t)tid * 8, en.sym1, v);
+                    KHG_UNROLL
+                    for (int i = 0; i < 8; ++i) {
+                        if (i < nv) {
+                            const uint64_t c = khg_pack_code_lds(sh.hot, ctab, v[i]);
+                            const uint32_t len = (uint32_t)(c >> 56);
+                            khg_pack_put(sh.words, pos, c & 0x00FFFFFFFFFFFFFFull, len);
+                            pos += len;
+                        }
+                    }
+                }
+            }
+        }
+        KHG_BARRIER();
+        KHG_FOR_THREADS(256)
+        {
+            const uint32_t carry = sh.carry[j & 1];
+            const uint32_t ncomplete = (r + bits) >> 5, rem = (r + bits) & 31;
+            const uint32_t nwrite = ncomplete + ((last && rem) ? 1 : 0);
+            const uint64_t w0 = start >> 5;
+            const bool fits = (w0 + nwrite) * 4 <= a.cap;
+            if (!fits && tid == 0 && nwrite) khg_set_status(&a.res->status, -2);
+            const uint32_t carry_hi = r ? (carry & ((1u << r) - 1)) << (32 - r) : 0;  // the r bits before `start`
+            uint32_t* out32 = (uint32_t*)a.out + w0;
+            for (uint32_t k = (uint32_t)tid; k <= ncomplete; k += 256) {
+                uint32_t v;
+                if (r == 0) {
+                    v = sh.words[k];
+                } else {
+                    const uint32_t hi = k == 0 ? carry_hi : sh.words[k - 1] << (32 - r);
+                    v = hi | (sh.words[k] >> r);
+                }
+                if (k < nwrite && fits) out32[k] = khg_bswap32(v);  // first stream bit = MSB of the first byte
+                if (k == ncomplete) sh.carry[(j + 1) & 1] = rem ? v >> (32 - rem) : 0;  // left to the next chunk
+            }
+        }
+        KHG_BARRIER();
+    }
+}
+
+// Header (Writer.h:9-23) and tables (Writer.h:34-41) behind the streams the single-pass packer wrote.  One
+// workgroup of 1024 threads.
+KHG_DEV void khg_meta_body(const KhgEncArgs& a, KhgScanSmem& sh)
+{
+    KHG_FOR_THREADS(1024)
+    {
+        if (tid == 0) {
+            KhgResult* res = a.res;
+            int ok = res->status == 0;
+            uint64_t off = 36 * 8;
+            for (int p = 0; p < 3; ++p) {
+                if (res->bits[p] < 0) {  // HeaderInfo lengths are int (Type.h:5)
+                    khg_set_status(&res->status, -4);
+                    ok = 0;
+                }
+                off += (uint64_t)(uint32_t)res->bits[p];
+                res->k[p] = a.tab_k[p];
+            }
+            const uint64_t table_off = off >> 3;
+            const uint64_t total = table_off + 8ull * ((uint64_t)a.tab_k[0] + a.tab_k[1] + a.tab_k[2]);
+            res->total_len = total;
+            if (ok && ((total + 3) & ~3ull) > a.cap) {
+                khg_set_status(&res->status, -2);
+                ok = 0;
+            }
+            sh.table_off = table_off;
+            sh.ok = ok;
+            res->ok_to_pack = ok;
+            if (ok) {
+                uint8_t* o = a.out;
+                khg_store_le32(o + 0, res->bits[0]);
+                khg_store_le32(o + 4, res->bits[1]);
+                khg_store_le32(o + 8, res->bits[2]);
+                khg_store_le32(o + 12, res->k[0]);
+                khg_store_le32(o + 16, res->k[1]);
+                khg_store_le32(o + 20, res->k[2]);
+                khg_store_le32(o + 24, a.rows);
+                khg_store_le32(o + 28, a.cols);
+                o[32] = (uint8_t)res->pads[0];
+                o[33] = (uint8_t)res->pads[1];
+                o[34] = (uint8_t)res->pads[2];
+                o[35] = (uint8_t)a.lvl;
+            }
+        }
+    }
+    KHG_BARRIER();
+    KHG_FOR_THREADS(1024)
+    {
+        if (sh.ok) {
+            uint8_t* tb = a.out + sh.table_off;
+            uint32_t kk[3] = {(uint32_t)a.tab_k[0], (uint32_t)a.tab_k[1], (uint32_t)a.tab_k[2]};
+            uint32_t tot = kk[0] + kk[1] + kk[2];
+            for (uint32_t e = (uint32_t)tid; e < tot; e += 1024) {
+                int p = e >= kk[0] + kk[1] ? 2 : e >= kk[0] ? 1 : 0;
+                uint32_t i = e - (p == 2 ? kk[0] + kk[1] : p == 1 ? kk[0] : 0);
+                khg_store_le32(tb + 8 * (size_t)e, a.tab_cnt[(size_t)p * KHG_NBINS + i]);
+                khg_store_le32(tb + 8 * (size_t)e + 4, a.tab_sym[(size_t)p * KHG_NBINS + i]);
+            }
         }
     }
 }

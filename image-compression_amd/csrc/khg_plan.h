@@ -65,6 +65,7 @@ struct KhgWorkspace {
     int32_t* tree_root;   // [3]
     uint32_t* chunk_bits; // [max chunks]
     uint64_t* chunk_off;  // [max chunks]
+    uint64_t* chain;      // [KHG_CHAIN_HEAD + 2 * (max chunks + 3)]: state of the single-pass packer (khg_packscan_body)
     KhgResult* res;
 };
 
@@ -81,7 +82,7 @@ static inline uint32_t khg_plane_chunks(int prow, int pcol, int nranks)
 
 // Byte sizes of the workspace arrays for images up to rows x cols.
 struct KhgWorkspaceSizes {
-    size_t ll[3], sym[3], hist, tab, codetab, big_scratch, tree, chunk_bits, chunk_off;
+    size_t ll[3], sym[3], hist, tab, codetab, big_scratch, tree, chunk_bits, chunk_off, chain;
 };
 static inline void khg_workspace_sizes(int rows, int cols, KhgWorkspaceSizes* s)
 {
@@ -101,6 +102,7 @@ static inline void khg_workspace_sizes(int rows, int cols, KhgWorkspaceSizes* s)
     if (nch_tiled > nch) nch = nch_tiled;
     s->chunk_bits = nch * sizeof(uint32_t);
     s->chunk_off = nch * sizeof(uint64_t);
+    s->chain = (KHG_CHAIN_HEAD + 4 * (nch + 3)) * sizeof(uint64_t);  // entry and group words: generous
 }
 
 // One tile of a row-tiled image: rank t of n owns image rows [rows*t/n, rows*(t+1)/n), rows/n a multiple of 8
@@ -308,12 +310,15 @@ static inline KhgEncArgs khg_enc_args(const KhgWorkspace& ws, int rows, int cols
         chunk += khg_plane_chunks(e.prow[p], e.pcol[p], tile.nranks);
     }
     e.nchunks = chunk;
+    e.chain_entries = 3;
+    for (int p = 0; p < 3; ++p) e.chain_entries += khg_chain_plane_entries((p < 2 ? e.chunk0[p + 1] : chunk) - e.chunk0[p]);
     e.rank = tile.rank;
     e.nranks = tile.nranks;
     e.write_meta = tile.rank == 0;
     for (int p = 0; p < 3; ++p) e.sym[p] = ws.sym[p];
     e.codetab = ws.codetab;
     e.chunk_bits = ws.chunk_bits; e.chunk_off = ws.chunk_off;
+    e.chain = ws.chain;
     e.tab_cnt = ws.tab_cnt; e.tab_sym = ws.tab_sym; e.tab_k = ws.tab_k;
     e.out = out;
     e.cap = cap & ~(size_t)3;

@@ -30,15 +30,49 @@ __global__ __launch_bounds__(256) void khg_table_kernel(KhgTableArgs a)
     khg_table_body(a, (int)blockIdx.x, sh);
 }
 
-// Start of an encode job: the dense histogram (counts 0, first raster indices "absent") and the result block, in
-// one launch (three fills were three dispatches on the job's critical path).
-__global__ __launch_bounds__(256) void khg_job_init_kernel(uint32_t* hist_cnt, uint32_t* hist_first, KhgResult* res)
+// Start of an encode job: the dense histogram (counts 0, first raster indices "absent"), the result block and the
+// state words of the single-pass packer, in one launch (three fills were three dispatches on the job's critical path).
+enum { KHG_INIT_HIST_WGS = 3 * KHG_NBINS / 4 / 256 };
+__global__ __launch_bounds__(256) void khg_job_init_kernel(uint32_t* hist_cnt, uint32_t* hist_first, KhgResult* res,
+                                                           uint64_t* chain, uint32_t chain_pairs)
 {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;  // grid covers 3 * KHG_NBINS / 4 vectors
     const uint4 zero = {0u, 0u, 0u, 0u}, ones = {~0u, ~0u, ~0u, ~0u};
-    ((uint4*)hist_cnt)[i] = zero;
-    ((uint4*)hist_first)[i] = ones;
-    if (i < sizeof(KhgResult) / 4) ((uint32_t*)res)[i] = 0;
+    if (blockIdx.x < KHG_INIT_HIST_WGS) {
+        const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+        ((uint4*)hist_cnt)[i] = zero;
+        ((uint4*)hist_first)[i] = ones;
+        if (i < sizeof(KhgResult) / 4) ((uint32_t*)res)[i] = 0;
+    } else {
+        const uint32_t i = (blockIdx.x - KHG_INIT_HIST_WGS) * 256u + threadIdx.x;
+        if (i < chain_pairs) ((uint4*)chain)[i] = zero;
+    }
+}
+
+static void khg_launch_job_init(const KhgWorkspace& ws, int rows, int cols, hipStream_t st)
+{
+    KhgWorkspace none;
+    memset(&none, 0, sizeof none);
+    const uint32_t entries = khg_enc_args(none, rows, cols, 0, nullptr, 0).chain_entries;
+    const uint32_t groups = (entries + KHG_CHAIN_GROUP - 1) / KHG_CHAIN_GROUP;
+    const uint32_t pairs = (KHG_CHAIN_HEAD + 2 * (entries + groups) + 1) / 2;  // 16-byte pairs of state words
+    hipLaunchKernelGGL(khg_job_init_kernel, dim3(KHG_INIT_HIST_WGS + (pairs + 255) / 256), dim3(256), 0, st, ws.hist_cnt,
+                       ws.hist_first, ws.res, ws.chain, pairs);
+}
+
+// khg_packscan_body: a workgroup draws its entry when it starts.
+__global__ __launch_bounds__(256) void khg_packscan_kernel(KhgEncArgs a)
+{
+    __shared__ KhgPackScanSmem sh;
+    __shared__ uint32_t ticket;
+    if (threadIdx.x == 0) ticket = (uint32_t)atomicAdd((unsigned long long*)a.chain, 1ull);
+    __syncthreads();
+    khg_packscan_body(a, ticket, sh);
+}
+
+__global__ __launch_bounds__(1024) void khg_meta_kernel(KhgEncArgs a)
+{
+    __shared__ KhgScanSmem sh;
+    khg_meta_body(a, sh);
 }
 
 __global__ __launch_bounds__(256) void khg_lens_kernel(KhgEncArgs a)
@@ -226,7 +260,7 @@ extern "C" int khg_ctx_create(int device, int max_rows, int max_cols, khg_ctx** 
     for (int p = 0; p < 3; ++p) { o_ll[p] = take(s.ll[p]); o_sym[p] = take(s.sym[p]); }
     size_t o_hc = take(s.hist), o_hf = take(s.hist), o_tc = take(s.tab), o_ts = take(s.tab), o_tk = take(64);
     size_t o_ct = take(s.codetab), o_bs = take(s.big_scratch), o_tl = take(s.tree), o_tr = take(s.tree), o_troot = take(64);
-    size_t o_cb = take(s.chunk_bits), o_co = take(s.chunk_off), o_res = take(sizeof(KhgResult));
+    size_t o_cb = take(s.chunk_bits), o_co = take(s.chunk_off), o_ch = take(s.chain), o_res = take(sizeof(KhgResult));
     size_t o_plane[3];
     for (int p = 0; p < 3; ++p) o_plane[p] = take(ds.plane[p]);
     size_t o_lut = take(ds.lut), o_lut2 = take(ds.lut2), o_blk = take(ds.blk), o_walk = take(ds.walk), o_hdr = take(sizeof(KhgDecHeader));
@@ -240,6 +274,7 @@ extern "C" int khg_ctx_create(int device, int max_rows, int max_cols, khg_ctx** 
     c->ws.codetab = (uint64_t*)(base + o_ct); c->ws.big_scratch = (uint32_t*)(base + o_bs);
     c->ws.tree_left = (int32_t*)(base + o_tl); c->ws.tree_right = (int32_t*)(base + o_tr); c->ws.tree_root = (int32_t*)(base + o_troot);
     c->ws.chunk_bits = (uint32_t*)(base + o_cb); c->ws.chunk_off = (uint64_t*)(base + o_co);
+    c->ws.chain = (uint64_t*)(base + o_ch);
     c->ws.res = (KhgResult*)(base + o_res);
     for (int p = 0; p < 3; ++p) c->dws.plane[p] = (double*)(base + o_plane[p]);
     c->dws.lut = (uint32_t*)(base + o_lut);
@@ -359,7 +394,7 @@ static int khg_enqueue_forward_ycbcr(khg_ctx* c, const double* const ycbcr[3], i
                                      double* const coef[3], hipStream_t st)
 {
     KhgWorkspace& ws = c->ws;
-    hipLaunchKernelGGL(khg_job_init_kernel, dim3(3 * KHG_NBINS / 4 / 256), dim3(256), 0, st, ws.hist_cnt, ws.hist_first, ws.res);
+    khg_launch_job_init(ws, rows, cols, st);
     khg_launch_fwd<KHG_FWD_PLANES1>(khg_fwd_args_planes(ws, rows, cols, lvl, 1, coef, KhgTile{0, 1}, ycbcr), st);
     khg_launch_fwd<KHG_FWD_PLANES2>(khg_fwd_args_planes(ws, rows, cols, lvl, 2, coef), st);
     KHG_HIP(hipGetLastError());
@@ -371,9 +406,8 @@ static int khg_enqueue_entropy(khg_ctx* c, int rows, int cols, int lvl, uint8_t*
     KhgTableArgs t = khg_table_args(c->ws);
     hipLaunchKernelGGL(khg_table_kernel, dim3(3), dim3(256), 0, st, t);
     KhgEncArgs e = khg_enc_args(c->ws, rows, cols, lvl, d_out, cap);
-    hipLaunchKernelGGL(khg_lens_kernel, dim3(e.nchunks), dim3(256), 0, st, e);
-    hipLaunchKernelGGL(khg_scan_kernel, dim3(1), dim3(1024), 0, st, e);
-    hipLaunchKernelGGL(khg_pack_kernel, dim3(e.nchunks), dim3(256), 0, st, e);
+    hipLaunchKernelGGL(khg_packscan_kernel, dim3(e.chain_entries), dim3(256), 0, st, e);
+    hipLaunchKernelGGL(khg_meta_kernel, dim3(1), dim3(1024), 0, st, e);
     KHG_HIP(hipGetLastError());
     KHG_HIP(hipMemcpyAsync(c->h_res, c->ws.res, sizeof(KhgResult), hipMemcpyDeviceToHost, st));
     return khg_end(c, st, 1);
@@ -384,7 +418,7 @@ static int khg_enqueue_forward(khg_ctx* c, const uint8_t* r, const uint8_t* g, c
                                int bgr_stride = 0)
 {
     KhgWorkspace& ws = c->ws;
-    hipLaunchKernelGGL(khg_job_init_kernel, dim3(3 * KHG_NBINS / 4 / 256), dim3(256), 0, st, ws.hist_cnt, ws.hist_first, ws.res);
+    khg_launch_job_init(ws, rows, cols, st);
     KhgFwdArgs a = khg_fwd_args_rgb(ws, r, g, b, rows, cols, lvl, coef, tile, false, bgr_stride);
     if (c->prof_on) {
         KHG_HIP(hipEventRecord(c->prof_e0, st));
@@ -557,7 +591,7 @@ extern "C" int khg_time_luma_forward_dev(khg_ctx* c, const uint8_t* d_r, const u
     KHG_HIP(hipSetDevice(c->device));
     if ((rc = khg_begin(c, st))) return rc;
     KhgWorkspace& ws = c->ws;
-    hipLaunchKernelGGL(khg_job_init_kernel, dim3(3 * KHG_NBINS / 4 / 256), dim3(256), 0, st, ws.hist_cnt, ws.hist_first, ws.res);
+    khg_launch_job_init(ws, rows, cols, st);
     KhgFwdArgs a = khg_fwd_args_rgb(ws, d_r, d_g, d_b, rows, cols, lvl, nullptr);
     hipEvent_t e0, e1;
     KHG_HIP(hipEventCreate(&e0));

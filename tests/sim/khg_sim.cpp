@@ -36,6 +36,7 @@ struct SimWs {
         ws.codetab = alloc<uint64_t>(s.codetab); ws.big_scratch = alloc<uint32_t>(s.big_scratch);
         ws.tree_left = alloc<int32_t>(s.tree); ws.tree_right = alloc<int32_t>(s.tree); ws.tree_root = alloc<int32_t>(16);
         ws.chunk_bits = alloc<uint32_t>(s.chunk_bits); ws.chunk_off = alloc<uint64_t>(s.chunk_off);
+        ws.chain = alloc<uint64_t>(s.chain);
         ws.res = alloc<KhgResult>(sizeof(KhgResult));
         KhgDecWorkspaceSizes d;
         khg_dec_workspace_sizes(rows, cols, &d);
@@ -84,6 +85,19 @@ int khgsim_forward(const uint8_t* r, const uint8_t* g, const uint8_t* b, int row
     return S.ws.res->status;
 }
 
+// khg_packscan_kernel + khg_meta_kernel: the entries of the chain one after another (tickets 0, 1, 2, ...), on state
+// words filled with junk first (the job-init launch zeroes them on the GPU; here only what the bodies rely on).
+static void sim_pack_single_pass(const KhgEncArgs& e) {
+    const uint32_t entries = e.chain_entries, groups = (entries + KHG_CHAIN_GROUP - 1) / KHG_CHAIN_GROUP;
+    memset(e.chain, 0, (KHG_CHAIN_HEAD + 2 * ((size_t)entries + groups)) * sizeof(uint64_t));
+    KhgPackScanSmem* psh = new KhgPackScanSmem;
+    for (uint32_t t = 0; t < entries; ++t) khg_packscan_body(e, t, *psh);
+    delete psh;
+    KhgScanSmem* ssh = new KhgScanSmem;
+    khg_meta_body(e, *ssh);
+    delete ssh;
+}
+
 static int sim_encode(SimWs& S, const uint8_t* r, const uint8_t* g, const uint8_t* b, int rows, int cols, int lvl,
                       uint8_t* out, size_t cap, size_t* out_len, int bgr_stride = 0) {
     forward_all(S, r, g, b, rows, cols, lvl, nullptr, KhgTile{0, 1}, bgr_stride);
@@ -92,14 +106,7 @@ static int sim_encode(SimWs& S, const uint8_t* r, const uint8_t* g, const uint8_
     for (int p = 0; p < 3; ++p) khg_table_body(t, p, *tsh);
     delete tsh;
     KhgEncArgs e = khg_enc_args(S.ws, rows, cols, lvl, out, cap);
-    KhgLensSmem lsh;
-    for (uint32_t c = 0; c < e.nchunks; ++c) khg_lens_body(e, c, lsh);
-    KhgScanSmem* ssh = new KhgScanSmem;
-    khg_scan_body(e, *ssh);
-    delete ssh;
-    KhgPackSmem* psh = new KhgPackSmem;
-    for (uint32_t c = 0; c < e.nchunks; ++c) khg_pack_body(e, c, *psh);
-    delete psh;
+    sim_pack_single_pass(e);
     if (out_len) *out_len = (size_t)S.ws.res->total_len;
     return S.ws.res->status;
 }
@@ -221,14 +228,7 @@ int khgsim_encode_ycbcr(const double* y, const double* cb, const double* cr, int
     for (int p = 0; p < 3; ++p) khg_table_body(t, p, *tsh);
     delete tsh;
     KhgEncArgs e = khg_enc_args(ws, rows, cols, lvl, out, cap);
-    KhgLensSmem lsh;
-    for (uint32_t c = 0; c < e.nchunks; ++c) khg_lens_body(e, c, lsh);
-    KhgScanSmem* ssh = new KhgScanSmem;
-    khg_scan_body(e, *ssh);
-    delete ssh;
-    KhgPackSmem* psh = new KhgPackSmem;
-    for (uint32_t c = 0; c < e.nchunks; ++c) khg_pack_body(e, c, *psh);
-    delete psh;
+    sim_pack_single_pass(e);
     if (out_len) *out_len = (size_t)ws.res->total_len;
     return ws.res->status;
 }

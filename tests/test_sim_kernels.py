@@ -39,6 +39,14 @@ def test_bmp_pixel_array_source_gives_the_same_bytes(shape, lvl):
     assert rc == 0 and comp == O.encode(rgb, lvl)
 
 
+def test_single_pass_packer_over_several_groups_of_entries():
+    """A frame large enough for the packer's chain to span three groups of 64 entries (147 entries): group bit
+    counts, group ends and the look-back across groups, against the oracle's bytes."""
+    rgb = synth_frame(1024, 1536, 9, 0)
+    rc, comp = S.encode(rgb, 1)
+    assert rc == 0 and comp == O.encode(rgb, 1)
+
+
 @pytest.mark.parametrize("name,lvl", [("cat", 1), ("couple", 0), ("library", 2), ("lena", 1), ("baboon", 0)])
 def test_run_images(run_images, name, lvl):
     rgb = run_images[name]

@@ -21,6 +21,7 @@ def model(px, comp):
         "khg_fwd_kernel<2>": (3.75 * px, "level 2 of Y, Cb, Cr: 3 LL f64 read + 0.75 symbols written"),
         "khg_lens_kernel": (3.0 * px, "symbols read"),
         "khg_pack_kernel": (3.0 * px + c, "symbols read + stream written"),
+        "khg_packscan_kernel": (3.0 * px + c, "symbols read + stream written (single pass: no measuring pass)"),
         "khg_dec_map_kernel<32>": (c + walk, "stream read + walk tables written"),
         "khg_dec_write_kernel": (c + c / 16 + 3.0 * px, "stream + walk column read, symbols written"),
         "khg_inv_kernel<0>": (3.75 * px, "level 2: 0.75 symbols read + 3 LL f64 written"),
