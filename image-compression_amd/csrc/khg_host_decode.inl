@@ -29,8 +29,9 @@ extern "C" int khg_peek(const uint8_t* comp, size_t len, khg_header* hdr)
 }
 
 // The inverse transform launches of a decode (symbols in the workspace): Decompress.h:274-280, Colorspace.h:25-36.
+// bgr_stride != 0: d_r is a BMP pixel array with that many bytes per row (whole images only), d_g and d_b are unused.
 static void khg_enqueue_inverse(khg_ctx* c, int rows, int cols, uint8_t* d_r, uint8_t* d_g, uint8_t* d_b, hipStream_t st,
-                                KhgTile tile, double* const ycbcr[3])
+                                KhgTile tile, double* const ycbcr[3], size_t bgr_stride = 0)
 {
     {  // Decompress.h:274-276: level 2 of the three components, one launch
         const KhgInvArgs a = khg_inv_args(c->ws, c->dws, rows, cols, 0, 3, 2, tile);
@@ -44,18 +45,23 @@ static void khg_enqueue_inverse(khg_ctx* c, int rows, int cols, uint8_t* d_r, ui
         hipLaunchKernelGGL((khg_inv_kernel<KHG_INV_PLANES1>), dim3(ac.nwg), dim3(256), 0, st, ac);
         KhgInvArgs ay = khg_inv_args(c->ws, c->dws, rows, cols, 0, 1, 1, tile);
         ay.r = d_r; ay.g = d_g; ay.b = d_b;
-        hipLaunchKernelGGL((khg_inv_kernel<KHG_INV_RGB>), dim3(ay.nwg), dim3(256), 0, st, ay);
+        ay.bgr_stride = bgr_stride;
+        if (bgr_stride) hipLaunchKernelGGL((khg_inv_kernel<KHG_INV_BGR>), dim3(ay.nwg), dim3(256), 0, st, ay);
+        else hipLaunchKernelGGL((khg_inv_kernel<KHG_INV_RGB>), dim3(ay.nwg), dim3(256), 0, st, ay);
     }
 }
 
 // ycbcr != null: stop before the colour conversion and leave the f64 planes there (DecompressImage's outputs).
 static int khg_decode_enqueue(khg_ctx* c, const uint8_t* d_comp, size_t len, int rows, int cols, uint8_t* d_r,
-                              uint8_t* d_g, uint8_t* d_b, void* stream, KhgTile tile, double* const ycbcr[3] = nullptr)
+                              uint8_t* d_g, uint8_t* d_b, void* stream, KhgTile tile, double* const ycbcr[3] = nullptr,
+                              size_t bgr_stride = 0)
 {
     int rc = khg_check_image(c, rows, cols);
     if (rc) return rc;
     if (!d_comp || ((uintptr_t)d_comp & 3)) return KHG_ERR_ARG;
-    if (!ycbcr && (!d_r || !d_g || !d_b || ((uintptr_t)d_r & 7) || ((uintptr_t)d_g & 7) || ((uintptr_t)d_b & 7)))
+    if (bgr_stride) {  // 16-bit stores at even byte offsets of the array
+        if (!d_r || ((uintptr_t)d_r & 1) || (bgr_stride & 1)) return KHG_ERR_ARG;
+    } else if (!ycbcr && (!d_r || !d_g || !d_b || ((uintptr_t)d_r & 7) || ((uintptr_t)d_g & 7) || ((uintptr_t)d_b & 7)))
         return KHG_ERR_ARG;
     if (len < 36 + 24) return KHG_ERR_FORMAT;
     hipStream_t st = (hipStream_t)stream;
@@ -72,7 +78,7 @@ static int khg_decode_enqueue(khg_ctx* c, const uint8_t* d_comp, size_t len, int
     hipLaunchKernelGGL((khg_dec_map_kernel<KHG_MAXOFF>), dim3(grid_dec), dim3(256), 0, st, d);
     hipLaunchKernelGGL(khg_dec_chain_kernel, dim3(3), dim3(256), 0, st, d);
     hipLaunchKernelGGL(khg_dec_write_kernel, dim3(grid_dec), dim3(256), 0, st, d);
-    khg_enqueue_inverse(c, rows, cols, d_r, d_g, d_b, st, tile, ycbcr);
+    khg_enqueue_inverse(c, rows, cols, d_r, d_g, d_b, st, tile, ycbcr, bgr_stride);
     KHG_HIP(hipGetLastError());
     KHG_HIP(hipMemcpyAsync(c->h_res, c->ws.res, sizeof(KhgResult), hipMemcpyDeviceToHost, st));
     return khg_end(c, st, 2);
@@ -82,6 +88,14 @@ extern "C" int khg_decode_dev(khg_ctx* c, const uint8_t* d_comp, size_t len, int
                               uint8_t* d_g, uint8_t* d_b, void* stream)
 {
     return khg_decode_enqueue(c, d_comp, len, rows, cols, d_r, d_g, d_b, stream, KhgTile{0, 1});
+}
+
+extern "C" int khg_decode_bgr_dev(khg_ctx* c, const uint8_t* d_comp, size_t len, int rows, int cols, uint8_t* d_pixels,
+                                  size_t stride, void* stream)
+{
+    if (!d_pixels) return KHG_ERR_ARG;
+    if (stride < 3 * (size_t)(cols > 0 ? cols : 0)) return KHG_ERR_DIMS;
+    return khg_decode_enqueue(c, d_comp, len, rows, cols, d_pixels, nullptr, nullptr, stream, KhgTile{0, 1}, nullptr, stride);
 }
 
 extern "C" int khg_decode_ycbcr_dev(khg_ctx* c, const uint8_t* d_comp, size_t len, int rows, int cols, double* d_y,

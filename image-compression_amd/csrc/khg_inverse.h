@@ -46,6 +46,9 @@ struct KhgInvArgs {
     // RGB variant (level 1 of the luma plane): the finished chroma planes and the output image
     const double *cb, *cr;    // (ph/2) x (pw/2)
     uint8_t *r, *g, *b;       // pitch pw
+    // BMP variant: the output is a 24-bit BMP pixel array instead (KhuGleSignal.cpp:285-293: B, G, R per pixel, image
+    // row y at row ph - 1 - y of the array); r = its first byte, bgr_stride = bytes per row of the array
+    size_t bgr_stride;
     KhgInvPlane pl[3];
 };
 
@@ -126,14 +129,18 @@ KHG_DEV void khg_rgb_pair(double y0, double y1, double Cb, double Cr, uint32_t r
     rgb[2] = khg_clamp_u8(y0 * 1 + bb) | (khg_clamp_u8(y1 * 1 + bb) << 8);
 }
 
+// Where the finished samples of a level-1 transform go: an f64 plane, the planar u8 image, or a BMP pixel array.
+enum { KHG_OUT_PLANE = 0, KHG_OUT_RGB = 1, KHG_OUT_BGR = 2 };
+
 KHG_DEV void khg_st16(uint8_t* p, uint32_t v) { const uint16_t h = (uint16_t)v; __builtin_memcpy(p, &h, 2); }
 
 // One workgroup: KHG_WG_STRIPS adjacent strips (one per wave) over one segment of output rows of plane pl.
-// RGB = true (level 1 of the luma plane only): the row phase does not store the luma samples but combines
+// OUT != KHG_OUT_PLANE (level 1 of the luma plane only): the row phase does not store the luma samples but combines
 // them with the already reconstructed chroma planes and writes the u8 image.
-template <int LEVEL, bool RGB>
+template <int LEVEL, int OUT>
 KHG_DEV void khg_inv_wg_body(const KhgInvArgs& a, const KhgInvPlane& pl, int wgl, KhgInvSmem<LEVEL>& sh)
 {
+    constexpr bool RGB = OUT != KHG_OUT_PLANE;
     typedef KhgInvSmem<LEVEL> SM;
     if (!a.hdr->ok) return;
     const int lvl = a.hdr->lvl;
@@ -305,10 +312,17 @@ KHG_DEV void khg_inv_wg_body(const KhgInvArgs& a, const KhgInvPlane& pl, int wgl
                     for (int rr = 0; rr < 2; ++rr) {
                         uint32_t rgb[3];
                         khg_rgb_pair(xe[rr], xo[rr], CB[KHG_SLOT], CR[KHG_SLOT], rgb);
-                        const uint32_t o = (uint32_t)(2 * m + rr - a.out_row0) * (uint32_t)pl.pw + 2u * (uint32_t)pair;
-                        khg_st16(a.r + o, rgb[0]);
-                        khg_st16(a.g + o, rgb[1]);
-                        khg_st16(a.b + o, rgb[2]);
+                        if (OUT == KHG_OUT_BGR) {  // B0 G0 R0 B1 G1 R1, rows bottom-up
+                            uint8_t* px = a.r + (size_t)(pl.ph - 1 - (2 * m + rr)) * a.bgr_stride + 6u * (uint32_t)pair;
+                            khg_st16(px, (rgb[2] & 255u) | ((rgb[1] & 255u) << 8));
+                            khg_st16(px + 2, (rgb[0] & 255u) | (rgb[2] & 0xFF00u));
+                            khg_st16(px + 4, (rgb[1] >> 8) | (rgb[0] & 0xFF00u));
+                        } else {
+                            const uint32_t o = (uint32_t)(2 * m + rr - a.out_row0) * (uint32_t)pl.pw + 2u * (uint32_t)pair;
+                            khg_st16(a.r + o, rgb[0]);
+                            khg_st16(a.g + o, rgb[1]);
+                            khg_st16(a.b + o, rgb[2]);
+                        }
                     }
                 } else {
                     KHG_UNROLL
@@ -327,15 +341,17 @@ KHG_DEV void khg_inv_wg_body(const KhgInvArgs& a, const KhgInvPlane& pl, int wgl
 }
 
 // Launch kinds: level 2 of the three components into their LL buffers; level 1 of planes into f64 planes (Cb and
-// Cr, or all three for the plane outputs of DecompressImage); level 1 of the luma plane into the RGB image.
-enum { KHG_INV_PLANES2 = 0, KHG_INV_PLANES1 = 1, KHG_INV_RGB = 2 };
+// Cr, or all three for the plane outputs of DecompressImage); level 1 of the luma plane into the RGB image or into
+// a BMP pixel array.
+enum { KHG_INV_PLANES2 = 0, KHG_INV_PLANES1 = 1, KHG_INV_RGB = 2, KHG_INV_BGR = 3 };
 
 template <int KIND>
 KHG_DEV void khg_inv_launch_body(const KhgInvArgs& a, int wg, KhgInvSmemAny& sh)
 {
     int p = 0;
     while (p + 1 < a.nplanes && wg >= a.pl[p + 1].wg0) ++p;
-    if constexpr (KIND == KHG_INV_PLANES2) khg_inv_wg_body<2, false>(a, a.pl[p], wg - a.pl[p].wg0, sh.l2);
-    else if constexpr (KIND == KHG_INV_PLANES1) khg_inv_wg_body<1, false>(a, a.pl[p], wg - a.pl[p].wg0, sh.l1);
-    else khg_inv_wg_body<1, true>(a, a.pl[p], wg - a.pl[p].wg0, sh.l1);
+    if constexpr (KIND == KHG_INV_PLANES2) khg_inv_wg_body<2, KHG_OUT_PLANE>(a, a.pl[p], wg - a.pl[p].wg0, sh.l2);
+    else if constexpr (KIND == KHG_INV_PLANES1) khg_inv_wg_body<1, KHG_OUT_PLANE>(a, a.pl[p], wg - a.pl[p].wg0, sh.l1);
+    else if constexpr (KIND == KHG_INV_RGB) khg_inv_wg_body<1, KHG_OUT_RGB>(a, a.pl[p], wg - a.pl[p].wg0, sh.l1);
+    else khg_inv_wg_body<1, KHG_OUT_BGR>(a, a.pl[p], wg - a.pl[p].wg0, sh.l1);
 }

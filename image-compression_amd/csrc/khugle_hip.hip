@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void khg_dec_write_kernel(KhgDecArgs a)
 }
 
 // KIND: KHG_INV_PLANES2 (level 2 of the three components), KHG_INV_PLANES1 (level 1 into f64 planes),
-// KHG_INV_RGB (level 1 of the luma plane into the RGB image).
+// KHG_INV_RGB / KHG_INV_BGR (level 1 of the luma plane into the planar RGB image / into a BMP pixel array).
 template <int KIND>
 __global__ __launch_bounds__(256) void khg_inv_kernel(KhgInvArgs a)
 {

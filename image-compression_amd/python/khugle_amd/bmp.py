@@ -67,6 +67,25 @@ def bmp24_pixels(path):
     return np.frombuffer(data, np.uint8, stride * height, off_bits), stride, width, height
 
 
+def bmp24_headers(width, height):
+    """The two headers SaveBmp puts in front of the pixel array (KhuGleSignal.cpp:295-319)."""
+    size = (width * 3 + 3) // 4 * 4 * height
+    header = struct.pack("<2sIHHI", b"BM", 54 + size, 0, 0, 54)
+    info = struct.pack("<IiiHHIIiiII", 40, width, height, 1, 24, 0, size, 2000, 2000, 0, 0)
+    return header + info
+
+
+def write_bmp24_pixels(path, pixels, width, height):
+    """A 24-bit BMP from its pixel array as Codec.decode_bgr_dev leaves it (B, G, R, rows bottom-up, rows of
+    (3 * width + 3) // 4 * 4 bytes)."""
+    pixels = np.asarray(pixels, np.uint8).reshape(-1)
+    if pixels.size != (width * 3 + 3) // 4 * 4 * height:
+        raise ValueError("pixel array does not match %dx%d" % (width, height))
+    with open(path, "wb") as f:
+        f.write(bmp24_headers(width, height))
+        f.write(pixels.tobytes())
+
+
 def write_bmp(path, rgb):
     rgb = np.asarray(rgb, np.uint8)
     _, height, width = rgb.shape
@@ -74,8 +93,4 @@ def write_bmp(path, rgb):
     rows = np.zeros((height, stride), np.uint8)
     bgr = rgb[::-1].transpose(1, 2, 0)  # (H, W, [B, G, R]), top-down
     rows[:, :width * 3] = bgr[::-1].reshape(height, width * 3)  # bottom-up
-    size = stride * height
-    header = struct.pack("<2sIHHI", b"BM", 54 + size, 0, 0, 54)
-    info = struct.pack("<IiiHHIIiiII", 40, width, height, 1, 24, 0, size, 2000, 2000, 0, 0)
-    with open(path, "wb") as f:
-        f.write(header + info + rows.tobytes())
+    write_bmp24_pixels(path, rows, width, height)

@@ -81,6 +81,15 @@ class Codec:
         _check(self.L.khg_decode_dev(self._ctx, _ptr(comp), length, rows, cols, _ptr(rgb_out[0]), _ptr(rgb_out[1]),
                                      _ptr(rgb_out[2]), _stream()), "decode_dev")
 
+    def decode_bgr_dev(self, comp, length, rows, cols, pixels, stride):
+        """Decode into the pixel array of a 24-bit BMP (uint8 cuda tensor of at least stride * rows bytes: B, G, R per
+        pixel, rows bottom-up): SaveBmp's pixel loop (KhuGleSignal.cpp:285-293) happens in the last kernel."""
+        assert comp.is_cuda and comp.dtype == self.torch.uint8 and comp.is_contiguous()
+        assert pixels.is_cuda and pixels.dtype == self.torch.uint8 and pixels.is_contiguous()
+        assert pixels.numel() >= stride * rows
+        _check(self.L.khg_decode_bgr_dev(self._ctx, _ptr(comp), length, rows, cols, _ptr(pixels), stride, _stream()),
+               "decode_bgr_dev")
+
     def last_status(self):
         return self.L.khg_last_status(self._ctx)
 

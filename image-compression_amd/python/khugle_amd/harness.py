@@ -8,7 +8,7 @@ import os
 
 import numpy as np
 
-from .bmp import bmp24_pixels, read_bmp, write_bmp
+from .bmp import bmp24_pixels, read_bmp, write_bmp, write_bmp24_pixels
 from .codec import Codec, peek
 
 PRESETS = {"normal": 0, "high": 1, "extreme": 2}
@@ -79,6 +79,28 @@ def load_comp(path, codec=None):
     return rgb, "%6.3fKB" % (len(comp) / 1024)
 
 
+def comp_to_bmp(comp_path, bmp_path, codec=None):
+    """LoadComp followed by the menu's "Save BMP" (SaveBmp, KhuGleSignal.cpp:277-334) without the planar picture in
+    between: the last decode kernel writes the file's pixel array, the host adds the two headers.  Returns LoadComp's
+    status line."""
+    with open(comp_path, "rb") as f:
+        comp = f.read()
+    hd = peek(comp)
+    c = _codec_for(hd.h, hd.w, codec)
+    t = c.torch
+    padded = np.zeros((len(comp) + 3) // 4 * 4, np.uint8)
+    padded[:len(comp)] = np.frombuffer(comp, np.uint8)
+    d_comp = t.from_numpy(padded).cuda(c.device)
+    stride = 3 * hd.w  # a multiple of 4: widths are multiples of 8
+    d_pix = t.empty(stride * hd.h, dtype=t.uint8, device=d_comp.device)
+    c.decode_bgr_dev(d_comp, len(comp), hd.h, hd.w, d_pix, stride)
+    rc = c.last_status()
+    if rc:
+        raise RuntimeError("decode_bgr_dev: status %d" % rc)
+    write_bmp24_pixels(bmp_path, d_pix.cpu().numpy(), hd.w, hd.h)
+    return "%6.3fKB" % (len(comp) / 1024)
+
+
 def main(argv=None):
     import argparse
     ap = argparse.ArgumentParser(prog="python -m khugle_amd", description="bmp <-> comp on an MI355X")
@@ -100,8 +122,7 @@ def main(argv=None):
         print(HEADER_STR)
         print(rep.value_str)
     else:
-        rgb, line = load_comp(args.comp)
-        write_bmp(args.bmp, rgb)
+        line = comp_to_bmp(args.comp, args.bmp)
         print("FILE SIZE")
         print(line)
     return 0

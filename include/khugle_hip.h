@@ -91,6 +91,13 @@ int khg_decode(khg_ctx *ctx, const uint8_t *comp, size_t len, uint8_t *r, uint8_
  * d_comp must be 4-byte aligned, d_r / d_g / d_b 8-byte aligned (KHG_ERR_ARG otherwise). */
 int khg_decode_dev(khg_ctx *ctx, const uint8_t *d_comp, size_t len, int rows, int cols,
                    uint8_t *d_r, uint8_t *d_g, uint8_t *d_b, void *stream);
+/* khg_decode_dev followed by the pixel loop of CKhuGleSignal::SaveBmp (KhuGleSignal.cpp:285-293), fused into the last
+ * inverse-transform kernel: the picture is written as the pixel array of a 24-bit BMP (B, G, R per pixel, image row y
+ * at row rows - 1 - y of the array, `stride` >= 3 * cols bytes per row; bytes of a row beyond 3 * cols are left as they
+ * are).  d_pixels 2-byte aligned, stride even.  With khugle_amd.bmp's header in front, the array is the file SaveBmp
+ * writes. */
+int khg_decode_bgr_dev(khg_ctx *ctx, const uint8_t *d_comp, size_t len, int rows, int cols, uint8_t *d_pixels,
+                       size_t stride, void *stream);
 /* Waits for the context's last enqueued work and returns its device-side status. */
 int khg_last_status(khg_ctx *ctx);
 

@@ -128,7 +128,7 @@ int khgsim_encode(const uint8_t* r, const uint8_t* g, const uint8_t* b, int rows
 
 // Mirrors khg_decode_dev / khg_tile_decode_dev (r, g, b receive the tile's rows only) / khg_decode_ycbcr_dev.
 static void sim_inverse(SimWs& S, int rows, int cols, uint8_t* r, uint8_t* g, uint8_t* b, KhgTile tile,
-                        double* const ycbcr[3]) {
+                        double* const ycbcr[3], size_t bgr_stride = 0) {
     KhgInvSmemAny* ish = new KhgInvSmemAny;
     {
         const KhgInvArgs a = khg_inv_args(S.ws, S.dws, rows, cols, 0, 3, 2, tile);
@@ -142,14 +142,18 @@ static void sim_inverse(SimWs& S, int rows, int cols, uint8_t* r, uint8_t* g, ui
         for (int wg = 0; wg < ac.nwg; ++wg) khg_inv_launch_body<KHG_INV_PLANES1>(ac, wg, *ish);
         KhgInvArgs ay = khg_inv_args(S.ws, S.dws, rows, cols, 0, 1, 1, tile);
         ay.r = r; ay.g = g; ay.b = b;
-        for (int wg = 0; wg < ay.nwg; ++wg) khg_inv_launch_body<KHG_INV_RGB>(ay, wg, *ish);
+        ay.bgr_stride = bgr_stride;
+        for (int wg = 0; wg < ay.nwg; ++wg) {
+            if (bgr_stride) khg_inv_launch_body<KHG_INV_BGR>(ay, wg, *ish);
+            else khg_inv_launch_body<KHG_INV_RGB>(ay, wg, *ish);
+        }
     }
     delete ish;
 }
 
 static int sim_decode(SimWs& S, const uint8_t* comp, size_t len, int rows, int cols, uint8_t* r, uint8_t* g, uint8_t* b,
                       int16_t* qy, int16_t* qcb, int16_t* qcr, int* passes_used, KhgTile tile,
-                      double* const ycbcr[3] = nullptr) {
+                      double* const ycbcr[3] = nullptr, size_t bgr_stride = 0) {
     std::vector<uint8_t> buf((len + 3) & ~(size_t)3, 0);
     memcpy(buf.data(), comp, len);
     KhgDecArgs d = khg_dec_args(S.ws, S.dws, buf.data(), len, rows, cols);
@@ -171,7 +175,7 @@ static int sim_decode(SimWs& S, const uint8_t* comp, size_t len, int rows, int c
     delete lsh2;
     delete wsh;
     delete ssh;
-    sim_inverse(S, rows, cols, r, g, b, tile, ycbcr);
+    sim_inverse(S, rows, cols, r, g, b, tile, ycbcr, bgr_stride);
     size_t ny = (size_t)rows * cols;
     if (qy) memcpy(qy, S.ws.sym[0], ny * 2);
     if (qcb) memcpy(qcb, S.ws.sym[1], ny / 4 * 2);
@@ -184,6 +188,14 @@ int khgsim_decode(const uint8_t* comp, size_t len, int rows, int cols, uint8_t* 
     if (!khg_dims_ok(rows, cols)) return -1;
     SimWs S(rows, cols);
     return sim_decode(S, comp, len, rows, cols, r, g, b, qy, qcb, qcr, passes_used, KhgTile{0, 1});
+}
+
+// Mirrors khg_decode_bgr_dev: the picture as a BMP pixel array of `stride` bytes per row.
+int khgsim_decode_bgr(const uint8_t* comp, size_t len, int rows, int cols, uint8_t* pixels, size_t stride) {
+    if (!khg_dims_ok(rows, cols) || stride < 3 * (size_t)cols || (stride & 1)) return -1;
+    SimWs S(rows, cols);
+    return sim_decode(S, comp, len, rows, cols, pixels, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                      KhgTile{0, 1}, nullptr, stride);
 }
 
 // ---- one long-lived workspace, as a khg_ctx has: jobs of any size up to its maximum, one after another, and a

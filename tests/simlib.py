@@ -34,6 +34,7 @@ def lib():
         L.khgsim_forward.argtypes = [_u8p, _u8p, _u8p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 6
         L.khgsim_decode.argtypes = [_u8p, C.c_size_t, C.c_int, C.c_int, _u8p, _u8p, _u8p, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.POINTER(C.c_int)]
+        L.khgsim_decode_bgr.argtypes = [_u8p, C.c_size_t, C.c_int, C.c_int, _u8p, C.c_size_t]
         L.khgsim_ssim.argtypes = [_u8p, _u8p, C.c_int, C.c_int, C.c_void_p]
         L.khgsim_ssim.restype = C.c_double
         L.khgsim_synth.argtypes = [_u8p, _u8p, _u8p, C.c_int, C.c_int, C.c_uint32, C.c_uint32]
@@ -134,6 +135,15 @@ def decode(comp, rows, cols):
     rc = lib().khgsim_decode(buf, buf.size, rows, cols, out[0], out[1], out[2], qy.ctypes.data, qcb.ctypes.data,
                              qcr.ctypes.data, C.byref(passes))
     return rc, out, (qy, qcb, qcr), passes.value
+
+
+def decode_bgr(comp, rows, cols, stride=None, fill=0x5C):
+    """The decoded picture as a 24-bit BMP pixel array (rows of `stride` bytes, pre-filled with `fill`)."""
+    buf = np.frombuffer(comp, np.uint8).copy()
+    stride = stride or 3 * cols
+    pixels = np.full(rows * stride, fill, np.uint8)
+    rc = lib().khgsim_decode_bgr(buf, buf.size, rows, cols, pixels, stride)
+    return rc, pixels
 
 
 def ssim(a, b):

@@ -91,6 +91,36 @@ def test_decode_dev_async(codec):
     assert np.array_equal(dec.cpu().numpy(), O.decode(out[:n].cpu().numpy().tobytes()))
 
 
+@pytest.mark.parametrize("shape,extra", [((8, 8), 0), ((24, 40), 6), ((264, 520), 0), ((1024, 1016), 2), ((2160, 3840), 0)])
+def test_decode_into_a_bmp_pixel_array(codec, shape, extra):
+    """khg_decode_bgr_dev: SaveBmp's pixel loop (KhuGleSignal.cpp:285-293) in the last decode kernel.  The array holds
+    the planar decode's picture (and the oracle's) B, G, R, bottom-up; bytes of a row past the pixels are untouched."""
+    import torch
+    import oracle_py as O
+    import simlib
+    from khugle_amd import synth_frame
+    from khugle_amd.lib import ERR_DIMS, KhgError
+    h, w = shape
+    rgb = synth_frame(h, w, 6, 1)
+    comp = codec.encode(rgb, 1)
+    want = codec.decode(comp)
+    if h * w <= 1 << 21:
+        assert np.array_equal(want, O.decode(comp))
+    padded = np.zeros((len(comp) + 3) // 4 * 4, np.uint8)
+    padded[:len(comp)] = np.frombuffer(comp, np.uint8)
+    d_comp = torch.from_numpy(padded).cuda()
+    stride = 3 * w + extra
+    d_pix = torch.full((h * stride,), 0x5C, dtype=torch.uint8, device="cuda")
+    codec.decode_bgr_dev(d_comp, len(comp), h, w, d_pix, stride)
+    assert codec.last_status() == 0
+    rows = d_pix.cpu().numpy().reshape(h, stride)
+    assert np.array_equal(rows[:, :3 * w], simlib.bgr_pixels(want)[0].reshape(h, -1)[:, :3 * w])
+    assert (rows[:, 3 * w:] == 0x5C).all()
+    with pytest.raises(KhgError) as e:  # rows shorter than the pixels
+        codec.decode_bgr_dev(d_comp, len(comp), h, w, d_pix, 3 * w - 2)
+    assert e.value.code == ERR_DIMS
+
+
 def test_fixed_length_codes(codec):
     """3-bit codes only (never self-synchronising) and a noise image: exact pixels either way."""
     import craft
@@ -157,8 +187,13 @@ def test_harness_reproduces_the_application_status_line(codec, tmp_path):
     assert open(out, "rb").read() == open(os.path.join(GOLDEN, "run", "cat_high.comp"), "rb").read()
     back = str(tmp_path / "cli.bmp")
     assert harness.main(["decompress", out, back]) == 0
-    from khugle_amd import read_bmp
-    assert np.array_equal(read_bmp(back), harness.load_comp(out, codec)[0])
+    from khugle_amd import read_bmp, write_bmp
+    decoded = harness.load_comp(out, codec)[0]
+    assert np.array_equal(read_bmp(back), decoded)
+    # ... and that file is byte for byte what SaveBmp writes for the planar picture
+    planar = str(tmp_path / "planar.bmp")
+    write_bmp(planar, decoded)
+    assert open(back, "rb").read() == open(planar, "rb").read()
 
 
 @pytest.mark.parametrize("shape", [(72, 136), (512, 520)])

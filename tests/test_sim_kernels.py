@@ -39,6 +39,21 @@ def test_bmp_pixel_array_source_gives_the_same_bytes(shape, lvl):
     assert rc == 0 and comp == O.encode(rgb, lvl)
 
 
+@pytest.mark.parametrize("shape,extra", [((8, 8), 0), ((16, 24), 6), ((264, 520), 0), ((256, 136), 2)])
+def test_decode_into_a_bmp_pixel_array(shape, extra):
+    """The last inverse kernel writing SaveBmp's pixel array (KhuGleSignal.cpp:285-293: B, G, R, rows bottom-up)
+    against the oracle's planar picture; bytes of a row beyond the pixels stay untouched."""
+    rgb = synth_frame(shape[0], shape[1], 6, 1)
+    comp = O.encode(rgb, 1)
+    want = O.decode(comp)
+    stride = 3 * shape[1] + extra
+    rc, pixels = S.decode_bgr(comp, shape[0], shape[1], stride, fill=0x5C)
+    assert rc == 0
+    rows = pixels.reshape(shape[0], stride)
+    assert np.array_equal(rows[:, :3 * shape[1]], S.bgr_pixels(want)[0].reshape(shape[0], -1)[:, :3 * shape[1]])
+    assert (rows[:, 3 * shape[1]:] == 0x5C).all()
+
+
 def test_single_pass_packer_over_several_groups_of_entries():
     """A frame large enough for the packer's chain to span three groups of 64 entries (147 entries): group bit
     counts, group ends and the look-back across groups, against the oracle's bytes."""
