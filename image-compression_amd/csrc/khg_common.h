@@ -36,6 +36,20 @@
         }                                          \
         (total) = run_;                            \
     }
+// Workgroup collective (NW waves, not inside KHG_FOR_THREADS): the sums of two doubles over all threads, to every
+// thread, for values whose sum does not depend on the order (integers below 2^53).  lds: a KhgWgSum2 nobody else
+// touches until the next barrier but one.
+#define KHG_WG_SUM2(av, bv, lds, NW, asum, bsum)       \
+    {                                                   \
+        double a_ = 0, b_ = 0;                          \
+        for (int t_ = 0; t_ < 64 * (NW); ++t_) {        \
+            a_ += (av)[t_];                             \
+            b_ += (bv)[t_];                             \
+        }                                               \
+        (void)(lds);                                    \
+        (asum) = a_;                                    \
+        (bsum) = b_;                                    \
+    }
 static inline uint32_t khg_atomic_add(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o + v; return o; }
 static inline uint32_t khg_atomic_min(uint32_t* p, uint32_t v) { uint32_t o = *p; if (v < o) *p = v; return o; }
 static inline uint32_t khg_atomic_or(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o | v; return o; }
@@ -96,6 +110,47 @@ __device__ __forceinline__ uint32_t khg_wave_incl_scan(uint32_t v)
         (excl)[0] = base_ + inc_ - (val)[0];                          \
         (total) = tot_;                                               \
     }
+// v + (v of the lanes the DPP control names); lanes the row mask excludes add zero.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double khg_dpp_add(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+    return v + __hiloint2double(hi, lo);
+}
+// The sum of v over the wave, valid in lane 63 (the order of the additions is the hardware's butterfly: for values
+// whose sum is exact in any order).
+__device__ __forceinline__ double khg_wave_sum_to_last(double v)
+{
+    v = khg_dpp_add<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
+    v = khg_dpp_add<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
+    v = khg_dpp_add<0x141, 0xf>(v);  // row_half_mirror
+    v = khg_dpp_add<0x140, 0xf>(v);  // row_mirror: every lane holds its row's sum
+    v = khg_dpp_add<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+    v = khg_dpp_add<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3
+    return v;
+}
+// Workgroup collective (NW waves, like KHG_BARRIER not inside KHG_FOR_THREADS): the sums of two doubles over all
+// threads, to every thread, for values whose sum does not depend on the order (integers below 2^53).  lds: a
+// KhgWgSum2 nobody else touches until the next barrier but one.
+#define KHG_WG_SUM2(av, bv, lds, NW, asum, bsum)                    \
+    {                                                                \
+        const double a_ = khg_wave_sum_to_last((av)[0]);             \
+        const double b_ = khg_wave_sum_to_last((bv)[0]);             \
+        if ((threadIdx.x & 63u) == 63u) {                            \
+            (lds).a[threadIdx.x >> 6] = a_;                          \
+            (lds).b[threadIdx.x >> 6] = b_;                          \
+        }                                                            \
+        __syncthreads();                                             \
+        double as_ = 0, bs_ = 0;                                     \
+        _Pragma("unroll") for (int w_ = 0; w_ < (NW); ++w_)         \
+        {                                                            \
+            as_ += (lds).a[w_];                                      \
+            bs_ += (lds).b[w_];                                      \
+        }                                                            \
+        (asum) = as_;                                                \
+        (bsum) = bs_;                                                \
+    }
 __device__ __forceinline__ uint32_t khg_atomic_add(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
 __device__ __forceinline__ uint32_t khg_atomic_min(uint32_t* p, uint32_t v) { return atomicMin(p, v); }
 __device__ __forceinline__ uint32_t khg_atomic_or(uint32_t* p, uint32_t v) { return atomicOr(p, v); }
@@ -114,6 +169,10 @@ __device__ __forceinline__ void khg_atomic_max64(unsigned long long* p, unsigned
 __device__ __forceinline__ uint64_t khg_chain_load(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void khg_chain_store(uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 #endif
+
+struct KhgWgSum2 {
+    double a[16], b[16];
+};
 
 // ---------------------------------------------------------------- constants
 

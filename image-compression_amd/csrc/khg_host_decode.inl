@@ -216,8 +216,8 @@ static int khg_ssim_enqueue(const uint8_t* d_a, const uint8_t* d_b, int width, i
     a.a = d_a; a.b = d_b; a.width = width; a.height = height; a.blocks = blocks;
     hipLaunchKernelGGL(khg_ssim_kernel, dim3((unsigned)((nblk + 255) / 256)), dim3(256), 0, st, a);
     KhgSsimMeanArgs m;
-    m.blocks = blocks; m.nblk = nblk; m.out = d_mean;
-    hipLaunchKernelGGL(khg_ssim_mean_kernel, dim3(1), dim3(256), 0, st, m);
+    m.blocks = blocks; m.nblk = nblk; m.out = d_mean; m.stat = nullptr;
+    hipLaunchKernelGGL(khg_ssim_mean_kernel, dim3(1), dim3(KHG_OSUM_NT), 0, st, m);
     KHG_HIP(hipGetLastError());
     return KHG_OK;
 }
@@ -233,6 +233,16 @@ extern "C" int khg_ssim_dev(khg_ctx* c, const uint8_t* d_a, const uint8_t* d_b, 
     if (rc) return rc;
     KHG_HIP(hipMemcpyAsync(ssim, c->ssim_mean, sizeof(double), hipMemcpyDeviceToHost, st));
     KHG_HIP(hipStreamSynchronize(st));
+    return KHG_OK;
+}
+
+extern "C" int khg_ordered_mean_dev(const double* d_values, size_t n, double* d_mean, void* stream)
+{
+    if (!d_values || !d_mean || n == 0) return KHG_ERR_ARG;
+    KhgSsimMeanArgs m;
+    m.blocks = d_values; m.nblk = n; m.out = d_mean; m.stat = nullptr;
+    hipLaunchKernelGGL(khg_ssim_mean_kernel, dim3(1), dim3(KHG_OSUM_NT), 0, (hipStream_t)stream, m);
+    KHG_HIP(hipGetLastError());
     return KHG_OK;
 }
 

@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void khg_ssim_kernel(KhgSsimArgs a)
     khg_ssim_body(a, blockIdx.x);
 }
 
-__global__ __launch_bounds__(256) void khg_ssim_mean_kernel(KhgSsimMeanArgs a)
+__global__ __launch_bounds__(KHG_OSUM_NT) void khg_ssim_mean_kernel(KhgSsimMeanArgs a)
 {
     __shared__ KhgSsimMeanSmem sh;
     khg_ssim_mean_body(a, sh);

@@ -40,6 +40,7 @@ SYMBOLS = [
     ("khg_comp_bound", C.c_size_t, [C.c_int, C.c_int]),
     ("khg_encode", C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     ("khg_encode_dev", C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_size_t, _P]),
+    ("khg_ordered_mean_dev", C.c_int, [_P, C.c_size_t, _P, _P]),
     ("khg_decode_bgr_dev", C.c_int, [_P, _P, C.c_size_t, C.c_int, C.c_int, _P, C.c_size_t, _P]),
     ("khg_encode_bgr_dev", C.c_int, [_P, _P, C.c_size_t, C.c_int, C.c_int, C.c_int, _P, C.c_size_t, _P]),
     ("khg_encode_result", C.c_int, [_P, C.POINTER(C.c_size_t)]),

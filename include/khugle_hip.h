@@ -117,13 +117,19 @@ int khg_decode_ycbcr_dev(khg_ctx *ctx, const uint8_t *d_comp, size_t len, int ro
 
 /* ---- quality metrics: ComputeSSIM (SSIM.h:57-72; the application passes the R channel only,
  * Main.cpp:250-253) and GetPsnr (KhuGleBase.cpp:613-627).  Device planes, synchronous result.
- * Per-block SSIM values are bit-exact; *ssim is their sum in raster order divided by the count, added up on the
- * device by one lane in the reference's order (SSIM.h:66-71), so it is bit-identical too. */
+ * Per-block SSIM values are bit-exact; *ssim is their sum in raster order divided by the count (SSIM.h:66-71),
+ * reproduced on the device with every rounding of that one-at-a-time sum (see khg_ordered_mean_dev), so it is
+ * bit-identical too. */
 int khg_ssim_dev(khg_ctx *ctx, const uint8_t *d_a, const uint8_t *d_b, int width, int height, double *ssim,
                  void *stream);
 int khg_psnr_dev(khg_ctx *ctx, const uint8_t *d_ir, const uint8_t *d_ig, const uint8_t *d_ib,
                  const uint8_t *d_or, const uint8_t *d_og, const uint8_t *d_ob, int width, int height, double *psnr,
                  void *stream);
+/* The last step of ComputeSSIM on its own (SSIM.h:66-71: the per-block values added one after another in raster
+ * order, then divided by their number): d_mean[0] = (((v[0] + v[1]) + v[2]) + ...) / n with every rounding of that
+ * loop, for any n >= 1 doubles in device memory.  Asynchronous on `stream`, no context, no allocation.  khg_ssim_dev
+ * ends with this kernel. */
+int khg_ordered_mean_dev(const double *d_values, size_t n, double *d_mean, void *stream);
 
 /* ---- an entry point that allocates nothing.  It has no counterpart in the reference: it exists for callers that
  * cannot allocate device or pinned memory -- code under HIP graph capture, tight serving loops, harnesses that

@@ -469,7 +469,20 @@ double khgsim_ssim(const uint8_t* a, const uint8_t* b, int width, int height, do
     if (blocks_out) memcpy(blocks_out, blocks.data(), nblk * sizeof(double));
     double mean = 0.0;
     KhgSsimMeanArgs m;
-    m.blocks = blocks.data(); m.nblk = nblk; m.out = &mean;
+    m.blocks = blocks.data(); m.nblk = nblk; m.out = &mean; m.stat = nullptr;
+    KhgSsimMeanSmem* msh = new KhgSsimMeanSmem;
+    khg_ssim_mean_body(m, *msh);
+    delete msh;
+    return mean;
+}
+
+// The mean kernel on any values: x[0] + x[1] + ... in that order, divided by n.  stat (optional, 3 counters): windows
+// summed as integers, windows scanned, values added one at a time.
+double khgsim_ordered_mean(const double* x, size_t n, unsigned long long* stat) {
+    double mean = 0.0;
+    if (stat) stat[0] = stat[1] = stat[2] = 0;
+    KhgSsimMeanArgs m;
+    m.blocks = x; m.nblk = n; m.out = &mean; m.stat = stat;
     KhgSsimMeanSmem* msh = new KhgSsimMeanSmem;
     khg_ssim_mean_body(m, *msh);
     delete msh;

@@ -37,6 +37,9 @@ def lib():
         L.khgsim_decode_bgr.argtypes = [_u8p, C.c_size_t, C.c_int, C.c_int, _u8p, C.c_size_t]
         L.khgsim_ssim.argtypes = [_u8p, _u8p, C.c_int, C.c_int, C.c_void_p]
         L.khgsim_ssim.restype = C.c_double
+        L.khgsim_ordered_mean.argtypes = [np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS"), C.c_size_t,
+                                          C.c_void_p]
+        L.khgsim_ordered_mean.restype = C.c_double
         L.khgsim_synth.argtypes = [_u8p, _u8p, _u8p, C.c_int, C.c_int, C.c_uint32, C.c_uint32]
         L.khgsim_synth.restype = None
         _f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
@@ -149,6 +152,14 @@ def decode_bgr(comp, rows, cols, stride=None, fill=0x5C):
 def ssim(a, b):
     a = np.ascontiguousarray(a, np.uint8); b = np.ascontiguousarray(b, np.uint8)
     return lib().khgsim_ssim(a, b, a.shape[1], a.shape[0], None)
+
+
+def ordered_mean(x):
+    """(mean, [integer windows, scanned windows, values added singly]) of the mean kernel on the doubles x."""
+    x = np.ascontiguousarray(x, np.float64)
+    stat = np.zeros(3, np.uint64)
+    m = lib().khgsim_ordered_mean(x, x.size, stat.ctypes.data)
+    return m, [int(v) for v in stat]
 
 
 def synth(rows, cols, seed, index):
