@@ -245,7 +245,7 @@ struct KhgQuant {
 };
 
 // Compress.h:215-218: q = (int)round(coef / (step * (lvl >= 1 ? a*(x+y)+b : 1)))
-KHG_DEV double khg_divisor(const KhgQuant& q, int band, int x, int y, int lvl)
+KHG_HOST_DEV double khg_divisor(const KhgQuant& q, int band, int x, int y, int lvl)
 {
     double div = q.step[band];
     if (lvl >= 1) {

@@ -54,7 +54,7 @@ static void khg_enqueue_inverse(khg_ctx* c, int rows, int cols, uint8_t* d_r, ui
 // ycbcr != null: stop before the colour conversion and leave the f64 planes there (DecompressImage's outputs).
 static int khg_decode_enqueue(khg_ctx* c, const uint8_t* d_comp, size_t len, int rows, int cols, uint8_t* d_r,
                               uint8_t* d_g, uint8_t* d_b, void* stream, KhgTile tile, double* const ycbcr[3] = nullptr,
-                              size_t bgr_stride = 0)
+                              size_t bgr_stride = 0, bool coeff_picture = false)
 {
     int rc = khg_check_image(c, rows, cols);
     if (rc) return rc;
@@ -78,7 +78,21 @@ static int khg_decode_enqueue(khg_ctx* c, const uint8_t* d_comp, size_t len, int
     hipLaunchKernelGGL((khg_dec_map_kernel<KHG_MAXOFF>), dim3(grid_dec), dim3(256), 0, st, d);
     hipLaunchKernelGGL(khg_dec_chain_kernel, dim3(3), dim3(256), 0, st, d);
     hipLaunchKernelGGL(khg_dec_write_kernel, dim3(grid_dec), dim3(256), 0, st, d);
-    khg_enqueue_inverse(c, rows, cols, d_r, d_g, d_b, st, tile, ycbcr, bgr_stride);
+    if (coeff_picture) {  // Decompress.h:234-262: the dequantised coefficients through the colour conversion, no IWT2D
+        KhgVisYccArgs v;
+        memset(&v, 0, sizeof v);
+        v.rows = rows; v.cols = cols;
+        for (int p = 0; p < 3; ++p) v.sym[p] = c->ws.sym[p];
+        v.hdr = c->dws.hdr;
+        for (int lvl = 0; lvl < 3; ++lvl) {
+            khg_make_quant(rows, cols, lvl, 0, &v.q[0][lvl]);
+            khg_make_quant(rows, cols, lvl, 1, &v.q[1][lvl]);
+        }
+        v.r = d_r; v.g = d_g; v.b = d_b;
+        hipLaunchKernelGGL(khg_vis_ycc_kernel, dim3((unsigned)(((size_t)rows * cols + 255) / 256)), dim3(256), 0, st, v);
+    } else {
+        khg_enqueue_inverse(c, rows, cols, d_r, d_g, d_b, st, tile, ycbcr, bgr_stride);
+    }
     KHG_HIP(hipGetLastError());
     KHG_HIP(hipMemcpyAsync(c->h_res, c->ws.res, sizeof(KhgResult), hipMemcpyDeviceToHost, st));
     return khg_end(c, st, 2);

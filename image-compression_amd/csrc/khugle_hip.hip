@@ -12,6 +12,7 @@
 #include "khg_plan.h"
 #include "khg_synth.h"
 #include "khg_dec_plan.h"
+#include "khg_visual.h"
 
 // ------------------------------------------------------------------ kernels
 
@@ -146,6 +147,10 @@ __global__ __launch_bounds__(256) void khg_inv_kernel(KhgInvArgs a)
     __shared__ KhgInvSmemAny sh;
     khg_inv_launch_body<KIND>(a, (int)blockIdx.x, sh);
 }
+
+__global__ __launch_bounds__(256) void khg_vis_ycc_kernel(KhgVisYccArgs a) { khg_vis_ycc_body(a, blockIdx.x); }
+__global__ __launch_bounds__(256) void khg_vis_step_kernel(KhgVisStepArgs a) { khg_vis_step_body(a, blockIdx.x); }
+__global__ __launch_bounds__(256) void khg_vis_bar_kernel(KhgVisBarArgs a) { khg_vis_bar_body(a, blockIdx.x); }
 
 __global__ __launch_bounds__(256) void khg_ssim_kernel(KhgSsimArgs a)
 {
@@ -646,3 +651,4 @@ extern "C" int khg_synth_rows_dev(uint8_t* d_r, uint8_t* d_g, uint8_t* d_b, int 
 #include "khg_host_decode.inl"
 #include "khg_host_tile.inl"
 #include "khg_host_batch.inl"
+#include "khg_host_visual.inl"

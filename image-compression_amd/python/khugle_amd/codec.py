@@ -90,6 +90,49 @@ class Codec:
         _check(self.L.khg_decode_bgr_dev(self._ctx, _ptr(comp), length, rows, cols, _ptr(pixels), stride, _stream()),
                "decode_bgr_dev")
 
+    # ---- what the application shows beside a result: two status lines and three pictures per direction
+    def status_strings(self, rows, cols, lvl, tables):
+        """("Step Size (min, max) : ...", "RLE Size (Y, Cb, Cr) : ...") of Compress.h:294-300 / Decompress.h:265-271;
+        tables = the three table sizes (the header's rle_*_len)."""
+        s1 = C.create_string_buffer(100)
+        s2 = C.create_string_buffer(100)
+        _check(self.L.khg_status_strings(rows, cols, lvl, int(tables[0]), int(tables[1]), int(tables[2]), s1, 100, s2,
+                                         100), "status_strings")
+        return s1.value.decode(), s2.value.decode()
+
+    def vis_coeffs_dev(self, rgb):
+        """Compress.h:108-141: the picture's DWT coefficient planes through YCbCr2RGB -> (3, H, W) uint8 cuda tensor."""
+        assert rgb.is_cuda and rgb.dtype == self.torch.uint8 and rgb.is_contiguous()
+        _, h, w = rgb.shape
+        out = self.torch.empty_like(rgb)
+        _check(self.L.khg_vis_coeffs_dev(self._ctx, _ptr(rgb[0]), _ptr(rgb[1]), _ptr(rgb[2]), h, w, _ptr(out[0]),
+                                         _ptr(out[1]), _ptr(out[2]), _stream()), "vis_coeffs_dev")
+        return out
+
+    def vis_dequant_dev(self, comp, length, rows, cols):
+        """Decompress.h:49-126, 234-262: a file's dequantised coefficients through YCbCr2RGB (no inverse transform)."""
+        assert comp.is_cuda and comp.dtype == self.torch.uint8 and comp.is_contiguous()
+        out = self.torch.empty((3, rows, cols), dtype=self.torch.uint8, device=comp.device)
+        _check(self.L.khg_vis_dequant_dev(self._ctx, _ptr(comp), length, rows, cols, _ptr(out[0]), _ptr(out[1]),
+                                          _ptr(out[2]), _stream()), "vis_dequant_dev")
+        _check(self.last_status(), "vis_dequant_dev")
+        return out
+
+    def vis_steps_dev(self, rows, cols, lvl):
+        """Compress.h:245-288: the quantiser's step sizes in red."""
+        out = self.torch.empty((3, rows, cols), dtype=self.torch.uint8, device=self.torch.device("cuda", self.device))
+        _check(self.L.khg_vis_steps_dev(rows, cols, lvl, _ptr(out[0]), _ptr(out[1]), _ptr(out[2]), _stream()),
+               "vis_steps_dev")
+        return out
+
+    def vis_bars_dev(self, rows, cols, len_bytes):
+        """Compress.h:330-391 / Decompress.h:128-188: the three stream lengths (bytes) as bars."""
+        out = self.torch.empty((3, rows, cols), dtype=self.torch.uint8, device=self.torch.device("cuda", self.device))
+        arr = (C.c_longlong * 3)(*[int(v) for v in len_bytes])
+        _check(self.L.khg_vis_bars_dev(rows, cols, arr, _ptr(out[0]), _ptr(out[1]), _ptr(out[2]), _stream()),
+               "vis_bars_dev")
+        return out
+
     def last_status(self):
         return self.L.khg_last_status(self._ctx)
 

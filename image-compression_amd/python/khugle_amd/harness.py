@@ -18,13 +18,16 @@ HEADER_STR = "PSNR         SSIM        FILE SIZE"  # Main.cpp:255
 class CompressReport:
     """What LoadBMPAndCompress leaves behind: the file image, the round-tripped picture and the status line."""
 
-    def __init__(self, comp, decoded, psnr, ssim, original_file_size):
+    def __init__(self, comp, decoded, psnr, ssim, original_file_size, step_str="", rle_str="", pictures=None):
         self.comp = comp
         self.decoded = decoded
         self.psnr = psnr
         self.ssim = ssim
         self.file_size = len(comp)
         self.original_file_size = original_file_size
+        self.step_str = step_str    # Compress.h:294-296
+        self.rle_str = rle_str      # Compress.h:299-300
+        self.pictures = pictures    # visualize=True: {"coefficients", "steps", "bars"} -> (3, H, W) u8
 
     @property
     def value_str(self):
@@ -39,8 +42,21 @@ def _codec_for(h, w, codec):
     return Codec(h, w)
 
 
-def load_bmp_and_compress(path, lvl, codec=None):
-    """Main.cpp:180-279.  lvl: 0 Normal, 1 High, 2 Extreme (or the names)."""
+def _pictures_of(c, comp, rows, cols, coefficients, padded):
+    """The three pictures beside a result: the coefficient picture given, the step sizes, the stream lengths.
+    padded: CompressImage draws the lengths with the pad bits, DecompressImage without."""
+    hd = peek(comp)
+    bits = [hd.y_len, hd.cb_len, hd.cr_len]
+    pads = [0, 0, 0] if padded else [hd.y_pad, hd.cb_pad, hd.cr_pad]
+    lens = [(b - p) // 8 for b, p in zip(bits, pads)]
+    return {"coefficients": coefficients.cpu().numpy(),
+            "steps": c.vis_steps_dev(rows, cols, hd.lvl).cpu().numpy(),
+            "bars": c.vis_bars_dev(rows, cols, lens).cpu().numpy()}
+
+
+def load_bmp_and_compress(path, lvl, codec=None, visualize=False):
+    """Main.cpp:180-279.  lvl: 0 Normal, 1 High, 2 Extreme (or the names).  visualize: also the three pictures the
+    application puts beside the result (Compress.h:116-141, 245-288, 330-391)."""
     lvl = PRESETS.get(str(lvl).lower(), lvl)
     rgb = read_bmp(path)
     _, h, w = rgb.shape
@@ -60,7 +76,10 @@ def load_bmp_and_compress(path, lvl, codec=None):
     d_out = t.from_numpy(decoded).cuda(c.device)
     psnr = c.psnr_dev(d_in, d_out)          # GetPsnr on R, G, B (Main.cpp:241-248)
     ssim = c.ssim_dev(d_in[0], d_out[0])    # ComputeSSIM on the R channel only (Main.cpp:250-253)
-    return CompressReport(comp, decoded, psnr, ssim, os.path.getsize(path))
+    hd = peek(comp)
+    step_str, rle_str = c.status_strings(h, w, lvl, (hd.rle_y_len, hd.rle_cb_len, hd.rle_cr_len))
+    pictures = _pictures_of(c, comp, h, w, c.vis_coeffs_dev(d_in), padded=True) if visualize else None
+    return CompressReport(comp, decoded, psnr, ssim, os.path.getsize(path), step_str, rle_str, pictures)
 
 
 def save_comp(report, path):
@@ -69,14 +88,24 @@ def save_comp(report, path):
         f.write(report.comp)
 
 
-def load_comp(path, codec=None):
-    """Main.cpp:281-334: returns the (3, H, W) u8 picture and the status line ("%6.3fKB")."""
+def load_comp(path, codec=None, visualize=False):
+    """Main.cpp:281-334: returns the (3, H, W) u8 picture and the status line ("%6.3fKB"); with visualize also
+    {"step_str", "rle_str", "pictures"}: DecompressImage's two lines and three pictures (Decompress.h:128-271)."""
     with open(path, "rb") as f:
         comp = f.read()
     hd = peek(comp)  # MeasureImageSize (Reader.h:97-110) plus validation
     c = _codec_for(hd.h, hd.w, codec)
     rgb = c.decode(comp)
-    return rgb, "%6.3fKB" % (len(comp) / 1024)
+    line = "%6.3fKB" % (len(comp) / 1024)
+    if not visualize:
+        return rgb, line
+    t = c.torch
+    padded = np.zeros((len(comp) + 3) // 4 * 4, np.uint8)
+    padded[:len(comp)] = np.frombuffer(comp, np.uint8)
+    d_comp = t.from_numpy(padded).cuda(c.device)
+    step_str, rle_str = c.status_strings(hd.h, hd.w, hd.lvl, (hd.rle_y_len, hd.rle_cb_len, hd.rle_cr_len))
+    pictures = _pictures_of(c, comp, hd.h, hd.w, c.vis_dequant_dev(d_comp, len(comp), hd.h, hd.w), padded=False)
+    return rgb, line, {"step_str": step_str, "rle_str": rle_str, "pictures": pictures}
 
 
 def comp_to_bmp(comp_path, bmp_path, codec=None):
@@ -110,19 +139,36 @@ def main(argv=None):
     a.add_argument("comp")
     a.add_argument("--preset", default="high", choices=sorted(PRESETS))
     a.add_argument("--save-decoded", help="also write the round-tripped picture as a 24-bit BMP")
+    a.add_argument("--pictures", help="directory for the three pictures the application shows beside the result")
     b = sub.add_parser("decompress", help=".comp -> BMP")
     b.add_argument("comp")
     b.add_argument("bmp")
+    b.add_argument("--pictures", help="directory for the three pictures the application shows beside the result")
     args = ap.parse_args(argv)
+
+    def save_pictures(directory, pictures):
+        os.makedirs(directory, exist_ok=True)
+        for name, rgb in pictures.items():
+            write_bmp(os.path.join(directory, name + ".bmp"), rgb)
+
     if args.cmd == "compress":
-        rep = load_bmp_and_compress(args.bmp, args.preset)
+        rep = load_bmp_and_compress(args.bmp, args.preset, visualize=bool(args.pictures))
         save_comp(rep, args.comp)
         if args.save_decoded:
             write_bmp(args.save_decoded, rep.decoded)
+        if args.pictures:
+            save_pictures(args.pictures, rep.pictures)
         print(HEADER_STR)
         print(rep.value_str)
+        print(rep.step_str)
+        print(rep.rle_str)
     else:
         line = comp_to_bmp(args.comp, args.bmp)
         print("FILE SIZE")
         print(line)
+        if args.pictures:
+            _, _, extra = load_comp(args.comp, visualize=True)
+            save_pictures(args.pictures, extra["pictures"])
+            print(extra["step_str"])
+            print(extra["rle_str"])
     return 0

@@ -131,6 +131,29 @@ int khg_psnr_dev(khg_ctx *ctx, const uint8_t *d_ir, const uint8_t *d_ig, const u
  * ends with this kernel. */
 int khg_ordered_mean_dev(const double *d_values, size_t n, double *d_mean, void *stream);
 
+/* ---- what the application shows beside a result (no part of the .comp file).
+ * khg_status_strings: the two status lines of CompressImage / DecompressImage (Compress.h:294-300,
+ * Decompress.h:265-271): "Step Size (min, max) : %.3f, %.3f" -- the extremes of the seven band steps at preset 0, of
+ * the per-position divisor over the luma plane at presets 1 and 2 -- and "RLE Size (Y, Cb, Cr) : %d, %d, %d" (the
+ * three table sizes, khg_header's rle_*_len).  Host only; either string may be NULL. */
+int khg_status_strings(int rows, int cols, int lvl, int k_y, int k_cb, int k_cr, char *step_str, size_t step_cap,
+                       char *rle_str, size_t rle_cap);
+/* The three pictures, as planar u8 R, G, B in device memory (rows x cols each), asynchronous on `stream`:
+ * - khg_vis_coeffs_dev: the DWT coefficient planes of the picture pushed through YCbCr2RGB (Compress.h:108-141);
+ * - khg_vis_dequant_dev: the same of a .comp file's dequantised coefficients (Decompress.h:49-126, 234-262), read
+ *   like khg_decode_dev (status through khg_last_status);
+ * - khg_vis_steps_dev: the quantiser's step sizes in red (Compress.h:245-288, Decompress.h:190-232);
+ * - khg_vis_bars_dev: the three stream lengths, in bytes, as bars (Compress.h:330-391 with the padded lengths,
+ *   Decompress.h:128-188 with the pad bits taken off first).  Where the reference would draw outside the picture
+ *   (rows > cols, or a stream of more than rows * rows bytes) nothing is drawn. */
+int khg_vis_coeffs_dev(khg_ctx *ctx, const uint8_t *d_r, const uint8_t *d_g, const uint8_t *d_b, int rows, int cols,
+                       uint8_t *d_out_r, uint8_t *d_out_g, uint8_t *d_out_b, void *stream);
+int khg_vis_dequant_dev(khg_ctx *ctx, const uint8_t *d_comp, size_t len, int rows, int cols, uint8_t *d_out_r,
+                        uint8_t *d_out_g, uint8_t *d_out_b, void *stream);
+int khg_vis_steps_dev(int rows, int cols, int lvl, uint8_t *d_out_r, uint8_t *d_out_g, uint8_t *d_out_b, void *stream);
+int khg_vis_bars_dev(int rows, int cols, const long long *len_bytes, uint8_t *d_out_r, uint8_t *d_out_g,
+                     uint8_t *d_out_b, void *stream);
+
 /* ---- an entry point that allocates nothing.  It has no counterpart in the reference: it exists for callers that
  * cannot allocate device or pinned memory -- code under HIP graph capture, tight serving loops, harnesses that
  * forbid hipMalloc -- and therefore cannot hold a khg_ctx either.  It is khg_ssim_dev with its scratch (the per-block

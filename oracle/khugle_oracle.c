@@ -8,6 +8,7 @@
 #include "khugle_oracle.h"
 
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -755,4 +756,95 @@ double khgo_psnr(const uint8_t *ir, const uint8_t *ig, const uint8_t *ib,
     double Mse = (MseR + MseG + MseB) / 3.;
     if (Mse == 0) return 100.;
     return 10 * log10(255 * 255 / Mse);
+}
+
+/* --------------------------------------- the application's by-product pictures */
+
+/* Compress.h:245-300 (Decompress.h:190-232, 265-271 are the same statements): the step sizes in red, their
+ * extremes in the first status line, the table sizes in the second.  str / str2: at least 100 bytes each (the
+ * reference's buffer), or NULL. */
+int khgo_vis_steps(int h, int w, int lvl, long k_y, long k_cb, long k_cr, uint8_t *r, uint8_t *g, uint8_t *b,
+                   char *str, char *str2)
+{
+    int rc = khgo_check_dims(h, w, lvl);
+    if (rc) return rc;
+    size_t n = (size_t)h * w;
+    double *step_size_2d = (double *)malloc(sizeof(double) * n);
+    if (!step_size_2d) return KHGO_ERR_NOMEM;
+    khgo_divisor_plane(h, w, lvl, 0, step_size_2d); /* Compress.h:216: step_size * (lvl >= 1 ? mul : 1) */
+    /* step_size_vec: Compress.h:172-199 */
+    double step_size_vec[7];
+    int h_half = h / 2, w_half = w / 2, h_qut = h / 4, w_qut = w / 4;
+    int map[7][4] = {
+        {0, h_qut, 0, w_qut},           {0, h_qut, w_qut, w_half},      {h_qut, h_half, 0, w_qut},
+        {h_qut, h_half, w_qut, w_half}, {0, h_half, w_half, w},         {h_half, h, 0, w_half},
+        {h_half, h, w_half, w}};
+    for (int index = 0; index < 7; index++) {
+        double rr = lvl == 0 ? 8 : lvl == 1 ? 10 : 12;
+        double i = 2;
+        double c = 8;
+        double f = lvl == 0 ? 23 : lvl == 1 ? 230 : 2300;
+        double tau = pow(2, rr - c + i) * (1 + f / pow(2, 11));
+        double step_size;
+        if (index == 0) step_size = tau / pow(2, i);
+        else if (index == 1 || index == 2) step_size = tau / pow(2, 2 - 1);
+        else if (index == 3) step_size = tau / pow(2, 2 - 2);
+        else if (index == 4 || index == 5) step_size = tau / pow(2, 1 - 1);
+        else step_size = tau / pow(2, 1 - 2);
+        step_size_vec[index] = step_size;
+    }
+    /* Compress.h:259-263 */
+    double max_step_size = step_size_vec[0], min_step_size = step_size_vec[0];
+    for (int i = 1; i < 7; i++) {
+        if (step_size_vec[i] > max_step_size) max_step_size = step_size_vec[i];
+        if (step_size_vec[i] < min_step_size) min_step_size = step_size_vec[i];
+    }
+    double max_step_size_2d = step_size_2d[0], min_step_size_2d = step_size_2d[0];
+    for (size_t i = 1; i < n; i++) {
+        if (step_size_2d[i] > max_step_size_2d) max_step_size_2d = step_size_2d[i];
+        if (step_size_2d[i] < min_step_size_2d) min_step_size_2d = step_size_2d[i];
+    }
+    if (r && g && b) {
+        for (int index = 0; index < 7; index++)
+            for (int y = map[index][0]; y < map[index][1]; y++)
+                for (int x = map[index][2]; x < map[index][3]; x++) {
+                    double nn = 0.0; /* Compress.h:274-288 */
+                    if (lvl >= 1) nn = (step_size_2d[(size_t)y * w + x] - min_step_size_2d) / max_step_size_2d;
+                    else nn = (step_size_vec[index] - min_step_size) / max_step_size;
+                    nn *= 255;
+                    r[(size_t)y * w + x] = (unsigned char)nn;
+                    g[(size_t)y * w + x] = 0;
+                    b[(size_t)y * w + x] = 0;
+                }
+    }
+    if (str) /* Compress.h:294-296 */
+        sprintf(str, "Step Size (min, max) : %.3f, %.3f", lvl >= 1 ? min_step_size_2d : min_step_size,
+                lvl >= 1 ? max_step_size_2d : max_step_size);
+    if (str2) /* Compress.h:299-300 */
+        sprintf(str2, "RLE Size (Y, Cb, Cr) : %d, %d, %d", (int)k_y, (int)k_cb, (int)k_cr);
+    free(step_size_2d);
+    return 0;
+}
+
+/* Compress.h:330-391 / Decompress.h:128-188: the three stream lengths (bytes) as bars, in unsigned char arithmetic.
+ * The reference writes whatever rows and columns its quotient and remainder by the image HEIGHT give, also outside
+ * the picture (undefined there); this restatement skips those positions. */
+int khgo_vis_bars(int h, int w, const long long *len, uint8_t *r, uint8_t *g, uint8_t *b)
+{
+    static const int add[3][3] = {{76, 149, 29}, {-43, -84, 127}, {127, -106, -20}};
+    for (size_t i = 0; i < (size_t)h * w; i++) r[i] = g[i] = b[i] = 0;
+    for (int c = 0; c < 3; c++) {
+        long long c_y = len[c] / h, c_x = len[c] % h;
+        for (long long y = 0; y < c_y; y++) {
+            long long max_x = (y == c_y - 1) ? c_x : w;
+            for (long long x = 0; x < max_x; x++) {
+                if (y >= h || x >= w) continue;
+                size_t p = (size_t)y * w + (size_t)x;
+                r[p] = (unsigned char)(r[p] + add[c][0]);
+                g[p] = (unsigned char)(g[p] + add[c][1]);
+                b[p] = (unsigned char)(b[p] + add[c][2]);
+            }
+        }
+    }
+    return 0;
 }

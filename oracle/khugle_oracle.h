@@ -117,6 +117,14 @@ long khgo_ssim_blocks(const uint8_t *a, const uint8_t *b, int width, int height,
 double khgo_psnr(const uint8_t *ir, const uint8_t *ig, const uint8_t *ib,
                  const uint8_t *or_, const uint8_t *og, const uint8_t *ob, int w, int h);
 
+/* The pictures and status lines the application shows beside a result.
+ * Compress.h:245-300: step sizes in red (r, g, b may be NULL), "Step Size (min, max) : ..." into str and
+ * "RLE Size (Y, Cb, Cr) : ..." into str2 (100 bytes each, or NULL). */
+int khgo_vis_steps(int h, int w, int lvl, long k_y, long k_cb, long k_cr, uint8_t *r, uint8_t *g, uint8_t *b,
+                   char *str, char *str2);
+/* Compress.h:330-391 / Decompress.h:128-188: the stream lengths (bytes) as bars. */
+int khgo_vis_bars(int h, int w, const long long *len, uint8_t *r, uint8_t *g, uint8_t *b);
+
 #ifdef __cplusplus
 }
 #endif

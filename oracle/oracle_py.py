@@ -66,6 +66,9 @@ def lib():
         L.khgo_ssim_blocks.restype = C.c_long
         L.khgo_psnr.argtypes = [_u8p] * 6 + [C.c_int, C.c_int]
         L.khgo_psnr.restype = C.c_double
+        L.khgo_vis_steps.argtypes = [C.c_int, C.c_int, C.c_int, C.c_long, C.c_long, C.c_long, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_char_p, C.c_char_p]
+        L.khgo_vis_bars.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_longlong), _u8p, _u8p, _u8p]
         _lib = L
     return _lib
 
@@ -209,3 +212,46 @@ def ssim_blocks(a, b):
 def psnr(rgb_in, rgb_out):
     i = np.ascontiguousarray(rgb_in, np.uint8); o = np.ascontiguousarray(rgb_out, np.uint8)
     return lib().khgo_psnr(i[0], i[1], i[2], o[0], o[1], o[2], i.shape[2], i.shape[1])
+
+
+def ycbcr_to_rgb(y, cb, cr):
+    """YCbCr2RGB (Colorspace.h:25-36) and the conversion to unsigned char, on any planes."""
+    y = np.ascontiguousarray(y, np.float64); cb = np.ascontiguousarray(cb, np.float64)
+    cr = np.ascontiguousarray(cr, np.float64)
+    h, w = y.shape
+    out = np.zeros((3, h, w), np.uint8)
+    lib().khgo_ycbcr_to_rgb(y, cb, cr, h, w, out[0], out[1], out[2])
+    return out
+
+
+def vis_coeffs(rgb):
+    """Compress.h:108-141: the DWT coefficient planes through the colour conversion."""
+    return ycbcr_to_rgb(*forward_planes(rgb))
+
+
+def vis_dequant(comp):
+    """Decompress.h:49-126, 234-262: the dequantised coefficients (before IWT2D) through the colour conversion."""
+    hd = peek(comp)
+    (qy, qcb, qcr), _ = decode_planes(comp)
+    dy = np.zeros((hd.h, hd.w)); dc = np.zeros((hd.h // 2, hd.w // 2))
+    lib().khgo_divisor_plane(hd.h, hd.w, hd.lvl, 0, dy)
+    lib().khgo_divisor_plane(hd.h, hd.w, hd.lvl, 1, dc)
+    return ycbcr_to_rgb(qy * dy, qcb * dc, qcr * dc)  # Decompress.h:105: one product per coefficient
+
+
+def vis_steps(h, w, lvl, tables=(0, 0, 0)):
+    """(picture, "Step Size ..." line, "RLE Size ..." line) of Compress.h:245-300."""
+    out = np.zeros((3, h, w), np.uint8)
+    s1 = C.create_string_buffer(100); s2 = C.create_string_buffer(100)
+    rc = lib().khgo_vis_steps(h, w, lvl, tables[0], tables[1], tables[2], out[0].ctypes.data, out[1].ctypes.data,
+                              out[2].ctypes.data, s1, s2)
+    if rc:
+        raise OracleError(rc)
+    return out, s1.value.decode(), s2.value.decode()
+
+
+def vis_bars(h, w, lens):
+    out = np.zeros((3, h, w), np.uint8)
+    arr = (C.c_longlong * 3)(*[int(v) for v in lens])
+    lib().khgo_vis_bars(h, w, arr, out[0], out[1], out[2])
+    return out

@@ -13,6 +13,7 @@
 #include "khg_plan.h"
 #include "khg_dec_plan.h"
 #include "khg_synth.h"
+#include "khg_visual.h"
 
 #ifndef KHG_SIM_SLACK
 #define KHG_SIM_SLACK 64  // bytes past each workspace array; 0 under AddressSanitizer to expose any overrun
@@ -196,6 +197,70 @@ int khgsim_decode_bgr(const uint8_t* comp, size_t len, int rows, int cols, uint8
     SimWs S(rows, cols);
     return sim_decode(S, comp, len, rows, cols, pixels, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
                       KhgTile{0, 1}, nullptr, stride);
+}
+
+// ---- the by-product pictures (khg_vis_*_dev)
+static void sim_vis_ycc(KhgVisYccArgs& v) {
+    const uint32_t nb = (uint32_t)(((size_t)v.rows * v.cols + 255) / 256);
+    for (uint32_t b_ = 0; b_ < nb; ++b_) khg_vis_ycc_body(v, b_);
+}
+int khgsim_vis_coeffs(const uint8_t* r, const uint8_t* g, const uint8_t* b, int rows, int cols, uint8_t* orr, uint8_t* og,
+                      uint8_t* ob) {
+    if (!khg_dims_ok(rows, cols)) return -1;
+    SimWs S(rows, cols);
+    const size_t n = (size_t)rows * cols;
+    std::vector<double> planes(n + n / 2);
+    double* coef[3] = {planes.data(), planes.data() + n, planes.data() + n + n / 4};
+    forward_all(S, r, g, b, rows, cols, 0, coef);
+    KhgVisYccArgs v;
+    memset(&v, 0, sizeof v);
+    v.rows = rows; v.cols = cols;
+    v.y = coef[0]; v.cb = coef[1]; v.cr = coef[2];
+    v.r = orr; v.g = og; v.b = ob;
+    sim_vis_ycc(v);
+    return 0;
+}
+int khgsim_vis_dequant(const uint8_t* comp, size_t len, int rows, int cols, uint8_t* orr, uint8_t* og, uint8_t* ob) {
+    if (!khg_dims_ok(rows, cols)) return -1;
+    SimWs S(rows, cols);
+    std::vector<uint8_t> scratch(3 * (size_t)rows * cols);
+    int rc = sim_decode(S, comp, len, rows, cols, scratch.data(), scratch.data() + (size_t)rows * cols,
+                        scratch.data() + 2 * (size_t)rows * cols, nullptr, nullptr, nullptr, nullptr, KhgTile{0, 1});
+    if (rc) return rc;
+    KhgVisYccArgs v;
+    memset(&v, 0, sizeof v);
+    v.rows = rows; v.cols = cols;
+    for (int p = 0; p < 3; ++p) v.sym[p] = S.ws.sym[p];
+    v.hdr = S.dws.hdr;
+    for (int lvl = 0; lvl < 3; ++lvl) {
+        khg_make_quant(rows, cols, lvl, 0, &v.q[0][lvl]);
+        khg_make_quant(rows, cols, lvl, 1, &v.q[1][lvl]);
+    }
+    v.r = orr; v.g = og; v.b = ob;
+    sim_vis_ycc(v);
+    return 0;
+}
+int khgsim_vis_steps(int rows, int cols, int lvl, uint8_t* r, uint8_t* g, uint8_t* b, double* lo_hi) {
+    if (!khg_dims_ok(rows, cols) || lvl < 0 || lvl > 2) return -1;
+    KhgVisStepArgs a;
+    a.rows = rows; a.cols = cols; a.lvl = lvl;
+    khg_make_quant(rows, cols, lvl, 0, &a.q);
+    khg_vis_step_range(rows, cols, lvl, a.q, &a.lo, &a.hi);
+    a.r = r; a.g = g; a.b = b;
+    const uint32_t nb = (uint32_t)(((size_t)rows * cols + 255) / 256);
+    for (uint32_t b_ = 0; b_ < nb; ++b_) khg_vis_step_body(a, b_);
+    if (lo_hi) { lo_hi[0] = a.lo; lo_hi[1] = a.hi; }
+    return 0;
+}
+int khgsim_vis_bars(int rows, int cols, const long long* len, uint8_t* r, uint8_t* g, uint8_t* b) {
+    if (!khg_dims_ok(rows, cols)) return -1;
+    KhgVisBarArgs a;
+    a.rows = rows; a.cols = cols;
+    for (int c = 0; c < 3; ++c) a.len[c] = len[c];
+    a.r = r; a.g = g; a.b = b;
+    const uint32_t nb = (uint32_t)(((size_t)rows * cols + 255) / 256);
+    for (uint32_t b_ = 0; b_ < nb; ++b_) khg_vis_bar_body(a, b_);
+    return 0;
 }
 
 // ---- one long-lived workspace, as a khg_ctx has: jobs of any size up to its maximum, one after another, and a

@@ -37,6 +37,10 @@ def lib():
         L.khgsim_decode_bgr.argtypes = [_u8p, C.c_size_t, C.c_int, C.c_int, _u8p, C.c_size_t]
         L.khgsim_ssim.argtypes = [_u8p, _u8p, C.c_int, C.c_int, C.c_void_p]
         L.khgsim_ssim.restype = C.c_double
+        L.khgsim_vis_coeffs.argtypes = [_u8p, _u8p, _u8p, C.c_int, C.c_int, _u8p, _u8p, _u8p]
+        L.khgsim_vis_dequant.argtypes = [_u8p, C.c_size_t, C.c_int, C.c_int, _u8p, _u8p, _u8p]
+        L.khgsim_vis_steps.argtypes = [C.c_int, C.c_int, C.c_int, _u8p, _u8p, _u8p, C.c_void_p]
+        L.khgsim_vis_bars.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_longlong), _u8p, _u8p, _u8p]
         L.khgsim_ordered_mean.argtypes = [np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS"), C.c_size_t,
                                           C.c_void_p]
         L.khgsim_ordered_mean.restype = C.c_double
@@ -152,6 +156,33 @@ def decode_bgr(comp, rows, cols, stride=None, fill=0x5C):
 def ssim(a, b):
     a = np.ascontiguousarray(a, np.uint8); b = np.ascontiguousarray(b, np.uint8)
     return lib().khgsim_ssim(a, b, a.shape[1], a.shape[0], None)
+
+
+def vis_coeffs(rgb):
+    out = np.zeros_like(rgb)
+    rc = lib().khgsim_vis_coeffs(rgb[0], rgb[1], rgb[2], rgb.shape[1], rgb.shape[2], out[0], out[1], out[2])
+    return rc, out
+
+
+def vis_dequant(comp, rows, cols):
+    buf = np.frombuffer(comp, np.uint8).copy()
+    out = np.zeros((3, rows, cols), np.uint8)
+    rc = lib().khgsim_vis_dequant(buf, buf.size, rows, cols, out[0], out[1], out[2])
+    return rc, out
+
+
+def vis_steps(rows, cols, lvl):
+    out = np.full((3, rows, cols), 7, np.uint8)
+    lo_hi = np.zeros(2)
+    rc = lib().khgsim_vis_steps(rows, cols, lvl, out[0], out[1], out[2], lo_hi.ctypes.data)
+    return rc, out, (float(lo_hi[0]), float(lo_hi[1]))
+
+
+def vis_bars(rows, cols, lens):
+    out = np.full((3, rows, cols), 7, np.uint8)
+    arr = (C.c_longlong * 3)(*[int(v) for v in lens])
+    rc = lib().khgsim_vis_bars(rows, cols, arr, out[0], out[1], out[2])
+    return rc, out
 
 
 def ordered_mean(x):
