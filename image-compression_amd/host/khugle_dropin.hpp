@@ -173,12 +173,27 @@ inline void CompressImage(std::unique_ptr<CompResult>& res, double** InputY, dou
     res = Parse(out.data(), len);
 }
 
-// The application's full argument list (Compress.h:104-106): out_image_vec, str and str2 receive nothing.
+namespace detail {
+// The two status lines of Compress.h:294-300 / Decompress.h:265-271.
+inline void status_lines(const HeaderInfo& i, std::string& str, std::string& str2)
+{
+    char a[100], b[100];
+    check(khg_status_strings(i.h, i.w, i.lvl, i.rle_y_len, i.rle_cb_len, i.rle_cr_len, a, sizeof a, b, sizeof b),
+          "khg_status_strings");
+    str = a;
+    str2 = b;
+}
+}  // namespace detail
+
+// The application's full argument list (Compress.h:104-106): str and str2 receive the two status lines;
+// out_image_vec is left alone (its pictures come from khg_vis_coeffs_dev / khg_vis_steps_dev / khg_vis_bars_dev as
+// planar u8 device memory, which the caller copies into its CKhuGleSignal rows).
 template <class ImageVec>
 inline void CompressImage(std::unique_ptr<CompResult>& res, double** InputY, double** InputCb, double** InputCr,
-                          int img_height, int img_width, int lvl, ImageVec&, std::string&, std::string&)
+                          int img_height, int img_width, int lvl, ImageVec&, std::string& str, std::string& str2)
 {
     CompressImage(res, InputY, InputCb, InputCr, img_height, img_width, lvl);
+    detail::status_lines(res->info_, str, str2);
 }
 
 // Decompress.h:7 with visualize = false.
@@ -217,6 +232,22 @@ inline void DecompressImage(const char* read_path, double** OutY, double** OutCb
 {
     std::unique_ptr<CompResult> r(ReadAll(read_path));
     DecompressImage(r.get(), OutY, OutCb, OutCr);
+}
+
+// Decompress.h:7 / 285 with the GUI arguments: the status lines as above when visualize is set.
+template <class ImageVec>
+inline void DecompressImage(const CompResult* result, double** OutY, double** OutCb, double** OutCr, bool visualize,
+                            ImageVec&, std::string& str, std::string& str2)
+{
+    DecompressImage(result, OutY, OutCb, OutCr);
+    if (visualize) detail::status_lines(result->info_, str, str2);
+}
+template <class ImageVec>
+inline void DecompressImage(const char* read_path, double** OutY, double** OutCb, double** OutCr, ImageVec& v,
+                            std::string& str, std::string& str2)
+{
+    std::unique_ptr<CompResult> r(ReadAll(read_path));
+    DecompressImage(r.get(), OutY, OutCb, OutCr, true, v, str, str2);
 }
 
 }  // namespace khugle_hip

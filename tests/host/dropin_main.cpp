@@ -59,7 +59,10 @@ int main(int argc, char** argv)
         dump(f, Y, rows, cols); dump(f, Cb, rows / 2, cols / 2); dump(f, Cr, rows / 2, cols / 2);
         std::fclose(f);
         double **OY = dmatrix(rows, cols), **OCb = dmatrix(rows / 2, cols / 2), **OCr = dmatrix(rows / 2, cols / 2);
-        khugle_hip::DecompressImage(argv[5], OY, OCb, OCr);
+        std::string d1, d2;
+        khugle_hip::DecompressImage(argv[5], OY, OCb, OCr, gui, d1, d2);
+        if (d1 != s1 || d2 != s2) throw std::runtime_error("status lines of the two directions differ");
+        std::printf("%s\n%s\n", s1.c_str(), s2.c_str());
         f = std::fopen(argv[7], "wb");
         dump(f, OY, rows, cols); dump(f, OCb, rows / 2, cols / 2); dump(f, OCr, rows / 2, cols / 2);
         std::fclose(f);

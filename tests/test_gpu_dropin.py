@@ -27,6 +27,7 @@ def _run(rgb, lvl, tmp_path):
         assert v.size == n + n // 2
         return v[:n].reshape(h, w), v[n:n + n // 4].reshape(h // 2, w // 2), v[n + n // 4:].reshape(h // 2, w // 2)
 
+    _run.lines = r.stdout.splitlines()  # the two status lines CompressImage / DecompressImage hand back
     return open(comp, "rb").read(), split(coef), split(planes)
 
 
@@ -42,6 +43,13 @@ def test_dropin_reproduces_the_reference_files(run_images, name, lvl, tmp_path):
         assert np.array_equal(got, want)
     for got, want in zip(planes, O.decode_planes(comp)[1]):  # DecompressImage's outputs
         assert np.array_equal(got, want)
+    hd = O.peek(comp)
+    assert _run.lines == list(O.vis_steps(hd.h, hd.w, lvl, (hd.rle_y_len, hd.rle_cb_len, hd.rle_cr_len))[1:])
+    if name == "cat":  # the lines of Pictures/High.png
+        import json
+        want = json.load(open(os.path.join(GOLDEN, "screenshots.json")))["presets"][str(lvl)]
+        assert _run.lines == ["Step Size (min, max) : %s, %s" % tuple(want["step"]),
+                              "RLE Size (Y, Cb, Cr) : %d, %d, %d" % tuple(want["tables"])]
 
 
 def test_dropin_rectangular(tmp_path):
