@@ -54,7 +54,7 @@ static void khg_enqueue_inverse(khg_ctx* c, int rows, int cols, uint8_t* d_r, ui
 // ycbcr != null: stop before the colour conversion and leave the f64 planes there (DecompressImage's outputs).
 static int khg_decode_enqueue(khg_ctx* c, const uint8_t* d_comp, size_t len, int rows, int cols, uint8_t* d_r,
                               uint8_t* d_g, uint8_t* d_b, void* stream, KhgTile tile, double* const ycbcr[3] = nullptr,
-                              size_t bgr_stride = 0, bool coeff_picture = false)
+                              size_t bgr_stride = 0, bool coeff_picture = false, bool indexed = false)
 {
     int rc = khg_check_image(c, rows, cols);
     if (rc) return rc;
@@ -74,9 +74,13 @@ static int khg_decode_enqueue(khg_ctx* c, const uint8_t* d_comp, size_t len, int
     // the three streams together are shorter than the file, and each ends inside one more workgroup at most
     uint64_t spanned = (8ull * len) / KHG_BLK_BITS + 3;
     const unsigned grid_dec = (unsigned)(spanned < d.nblocks ? spanned : d.nblocks);
-    hipLaunchKernelGGL((khg_dec_map_kernel<KHG_MAP_SMALL>), dim3(grid_dec), dim3(256), 0, st, d);
-    hipLaunchKernelGGL((khg_dec_map_kernel<KHG_MAXOFF>), dim3(grid_dec), dim3(256), 0, st, d);
-    hipLaunchKernelGGL(khg_dec_chain_kernel, dim3(3), dim3(256), 0, st, d);
+    if (indexed) {  // the file says where codewords start (khg_index.h); KHG_ERR_FORMAT if it does not
+        hipLaunchKernelGGL(khg_dec_index_kernel, dim3(grid_dec + 3), dim3(256), 0, st, d, grid_dec);
+    } else {
+        hipLaunchKernelGGL((khg_dec_map_kernel<KHG_MAP_SMALL>), dim3(grid_dec), dim3(256), 0, st, d);
+        hipLaunchKernelGGL((khg_dec_map_kernel<KHG_MAXOFF>), dim3(grid_dec), dim3(256), 0, st, d);
+        hipLaunchKernelGGL(khg_dec_chain_kernel, dim3(3), dim3(256), 0, st, d);
+    }
     hipLaunchKernelGGL(khg_dec_write_kernel, dim3(grid_dec), dim3(256), 0, st, d);
     if (coeff_picture) {  // Decompress.h:234-262: the dequantised coefficients through the colour conversion, no IWT2D
         KhgVisYccArgs v;
@@ -110,6 +114,12 @@ extern "C" int khg_decode_bgr_dev(khg_ctx* c, const uint8_t* d_comp, size_t len,
     if (!d_pixels) return KHG_ERR_ARG;
     if (stride < 3 * (size_t)(cols > 0 ? cols : 0)) return KHG_ERR_DIMS;
     return khg_decode_enqueue(c, d_comp, len, rows, cols, d_pixels, nullptr, nullptr, stream, KhgTile{0, 1}, nullptr, stride);
+}
+
+extern "C" int khg_decode_indexed_dev(khg_ctx* c, const uint8_t* d_comp, size_t len, int rows, int cols, uint8_t* d_r,
+                                      uint8_t* d_g, uint8_t* d_b, void* stream)
+{
+    return khg_decode_enqueue(c, d_comp, len, rows, cols, d_r, d_g, d_b, stream, KhgTile{0, 1}, nullptr, 0, false, true);
 }
 
 extern "C" int khg_decode_ycbcr_dev(khg_ctx* c, const uint8_t* d_comp, size_t len, int rows, int cols, double* d_y,

@@ -13,6 +13,7 @@
 #include "khg_synth.h"
 #include "khg_dec_plan.h"
 #include "khg_visual.h"
+#include "khg_index.h"
 
 // ------------------------------------------------------------------ kernels
 
@@ -148,6 +149,19 @@ __global__ __launch_bounds__(256) void khg_inv_kernel(KhgInvArgs a)
     khg_inv_launch_body<KIND>(a, (int)blockIdx.x, sh);
 }
 
+__global__ __launch_bounds__(256) void khg_index_kernel(KhgEncArgs a)
+{
+    __shared__ KhgIdxSmem sh;
+    khg_index_body(a, blockIdx.x, sh);
+}
+__global__ __launch_bounds__(256) void khg_index_meta_kernel(KhgEncArgs a) { khg_index_meta_body(a); }
+// Workgroups in the write launch's order, then one per plane.
+__global__ __launch_bounds__(256) void khg_dec_index_kernel(KhgDecArgs a, uint32_t nwrite)
+{
+    uint32_t blk = blockIdx.x < nwrite ? khg_dec_dispatch_order(a, blockIdx.x) : a.nblocks + (blockIdx.x - nwrite);
+    if (blk != ~0u) khg_dec_index_body(a, blk);
+}
+
 __global__ __launch_bounds__(256) void khg_vis_ycc_kernel(KhgVisYccArgs a) { khg_vis_ycc_body(a, blockIdx.x); }
 __global__ __launch_bounds__(256) void khg_vis_step_kernel(KhgVisStepArgs a) { khg_vis_step_body(a, blockIdx.x); }
 __global__ __launch_bounds__(256) void khg_vis_bar_kernel(KhgVisBarArgs a) { khg_vis_bar_body(a, blockIdx.x); }
@@ -214,6 +228,7 @@ struct khg_ctx {
     size_t tdec_len;
     uint32_t tdec_nb[3];  // active workgroups of each plane's stream
     int tdec_step;        // 0 none, 1 mapped, 2 written
+    int format;           // 1: the reference's file; 2: the same followed by a seek index (khg_ctx_set_format)
 };
 
 static size_t khg_align(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -250,6 +265,7 @@ extern "C" int khg_ctx_create(int device, int max_rows, int max_cols, khg_ctx** 
     khg_ctx* c = new (std::nothrow) khg_ctx;
     if (!c) return KHG_ERR_NOMEM;
     memset(c, 0, sizeof *c);
+    c->format = 1;
     c->device = device;
     c->max_rows = max_rows;
     c->max_cols = max_cols;
@@ -413,6 +429,10 @@ static int khg_enqueue_entropy(khg_ctx* c, int rows, int cols, int lvl, uint8_t*
     KhgEncArgs e = khg_enc_args(c->ws, rows, cols, lvl, d_out, cap);
     hipLaunchKernelGGL(khg_packscan_kernel, dim3(e.chain_entries), dim3(256), 0, st, e);
     hipLaunchKernelGGL(khg_meta_kernel, dim3(1), dim3(1024), 0, st, e);
+    if (c->format == 2) {  // the seek index behind the file (khg_index.h)
+        hipLaunchKernelGGL(khg_index_kernel, dim3(e.chain_entries), dim3(256), 0, st, e);
+        hipLaunchKernelGGL(khg_index_meta_kernel, dim3(1), dim3(256), 0, st, e);
+    }
     KHG_HIP(hipGetLastError());
     KHG_HIP(hipMemcpyAsync(c->h_res, c->ws.res, sizeof(KhgResult), hipMemcpyDeviceToHost, st));
     return khg_end(c, st, 1);
@@ -491,6 +511,21 @@ extern "C" int khg_encode_ycbcr_dev(khg_ctx* c, const double* d_y, const double*
     rc = khg_enqueue_forward_ycbcr(c, src, rows, cols, lvl, tap ? coef : nullptr, st);
     if (rc) return rc;
     return khg_enqueue_entropy(c, rows, cols, lvl, d_out, cap, st);
+}
+
+extern "C" int khg_ctx_set_format(khg_ctx* c, int format)
+{
+    if (!c || (format != 1 && format != 2)) return KHG_ERR_ARG;
+    c->format = format;
+    return KHG_OK;
+}
+
+extern "C" size_t khg_index_bound(int rows, int cols)
+{
+    if (!khg_dims_ok(rows, cols)) return 0;
+    // three streams of at most khg_comp_bound bytes together, each with one partly used entry at its end
+    const uint64_t entries = 8ull * khg_comp_bound_impl(rows, cols) / KHG_SUB_BITS + 3;
+    return (size_t)(8 + khg_idx_bytes(entries));
 }
 
 extern "C" int khg_encode_result(khg_ctx* c, size_t* out_len)

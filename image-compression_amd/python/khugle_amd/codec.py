@@ -90,6 +90,22 @@ class Codec:
         _check(self.L.khg_decode_bgr_dev(self._ctx, _ptr(comp), length, rows, cols, _ptr(pixels), stride, _stream()),
                "decode_bgr_dev")
 
+    # ---- format 2: the same file followed by a seek index
+    def set_format(self, fmt):
+        """1: the reference's file (default).  2: followed by a seek index (encode buffers then need comp_bound() +
+        index_bound() bytes; decode_indexed_dev reads such files)."""
+        _check(self.L.khg_ctx_set_format(self._ctx, int(fmt)), "ctx_set_format")
+
+    def index_bound(self, rows, cols):
+        return int(self.L.khg_index_bound(rows, cols))
+
+    def decode_indexed_dev(self, comp, length, rows, cols, rgb_out):
+        assert comp.is_cuda and comp.dtype == self.torch.uint8 and comp.is_contiguous()
+        assert rgb_out.is_cuda and rgb_out.dtype == self.torch.uint8 and rgb_out.is_contiguous()
+        assert tuple(rgb_out.shape) == (3, rows, cols)
+        _check(self.L.khg_decode_indexed_dev(self._ctx, _ptr(comp), length, rows, cols, _ptr(rgb_out[0]),
+                                             _ptr(rgb_out[1]), _ptr(rgb_out[2]), _stream()), "decode_indexed_dev")
+
     # ---- what the application shows beside a result: two status lines and three pictures per direction
     def status_strings(self, rows, cols, lvl, tables):
         """("Step Size (min, max) : ...", "RLE Size (Y, Cb, Cr) : ...") of Compress.h:294-300 / Decompress.h:265-271;

@@ -40,6 +40,9 @@ SYMBOLS = [
     ("khg_comp_bound", C.c_size_t, [C.c_int, C.c_int]),
     ("khg_encode", C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     ("khg_encode_dev", C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_size_t, _P]),
+    ("khg_ctx_set_format", C.c_int, [_P, C.c_int]),
+    ("khg_index_bound", C.c_size_t, [C.c_int, C.c_int]),
+    ("khg_decode_indexed_dev", C.c_int, [_P, _P, C.c_size_t, C.c_int, C.c_int, _P, _P, _P, _P]),
     ("khg_status_strings", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_size_t,
                                      C.c_char_p, C.c_size_t]),
     ("khg_vis_coeffs_dev", C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P]),

@@ -131,6 +131,21 @@ int khg_psnr_dev(khg_ctx *ctx, const uint8_t *d_ir, const uint8_t *d_ig, const u
  * ends with this kernel. */
 int khg_ordered_mean_dev(const double *d_values, size_t n, double *d_mean, void *stream);
 
+/* ---- format 2: the reference's file followed by a seek index.  No counterpart in the reference (its format has no
+ * synchronisation points; a decoder must first find where codewords begin).  After khg_ctx_set_format(ctx, 2) the
+ * whole-image encoders of the context (khg_encode*, not the khg_tile_* steps) append, behind the unchanged bytes of
+ * format 1 -- which ReadAll (Reader.h:56-74) reads as before, never looking further -- where the first codeword of
+ * every 256 bits of each stream starts and which symbol it is, plus both dimensions and 64-bit stream lengths (layout:
+ * csrc/khg_index.h).  The output buffer then needs khg_comp_bound + khg_index_bound bytes (KHG_ERR_CAP otherwise).
+ * khg_decode_indexed_dev is khg_decode_dev for such files: it starts its decoders from the index instead of searching
+ * for the codeword boundaries first (about a third of the decoder's work); a file without a sound index is refused
+ * (KHG_ERR_FORMAT through khg_last_status).  An index that lies about a sound stream yields wrong pixels, never an
+ * access outside the buffers.  khg_decode* ignore the index.  Format 1 is the default. */
+int khg_ctx_set_format(khg_ctx *ctx, int format);
+size_t khg_index_bound(int rows, int cols);
+int khg_decode_indexed_dev(khg_ctx *ctx, const uint8_t *d_comp, size_t len, int rows, int cols, uint8_t *d_r,
+                           uint8_t *d_g, uint8_t *d_b, void *stream);
+
 /* ---- what the application shows beside a result (no part of the .comp file).
  * khg_status_strings: the two status lines of CompressImage / DecompressImage (Compress.h:294-300,
  * Decompress.h:265-271): "Step Size (min, max) : %.3f, %.3f" -- the extremes of the seven band steps at preset 0, of

@@ -255,3 +255,50 @@ def vis_bars(h, w, lens):
     arr = (C.c_longlong * 3)(*[int(v) for v in lens])
     lib().khgo_vis_bars(h, w, arr, out[0], out[1], out[2])
     return out
+
+
+# ---- format 2 (no counterpart in the reference): the seek index behind a format-1 file, restated from its
+# definition -- entry s of a plane names the first symbol whose codeword starts at or behind bit 256 * s of the
+# plane's stream -- with the codeword positions taken from a plain cumulative sum of code lengths.
+IDX_SUB_BITS = 256
+
+
+def index_trailer(comp):
+    """The bytes that format 2 appends to the format-1 file `comp` (the zero gap up to a multiple of 8 included)."""
+    import struct
+    hd = peek(comp)
+    buf = np.frombuffer(comp, np.uint8)
+    (qy, qcb, qcr), _ = decode_planes(comp)
+    ks = [hd.rle_y_len, hd.rle_cb_len, hd.rle_cr_len]
+    bits = [hd.y_len - hd.y_pad, hd.cb_len - hd.cb_pad, hd.cr_len - hd.cr_pad]
+    table_off = 36 + (hd.y_len + hd.cb_len + hd.cr_len) // 8
+    firsts, offs, nsyms, nents = [], [], [], []
+    for p, q in enumerate((qy, qcb, qcr)):
+        tab = np.frombuffer(buf[table_off:table_off + 8 * ks[p]].tobytes(), "<i4").reshape(ks[p], 2)
+        table_off += 8 * ks[p]
+        counts, syms = tab[:, 0].copy(), tab[:, 1].copy()
+        _, lens = build_codes(counts, syms)
+        len_of = dict(zip(syms.tolist(), lens.tolist()))
+        flat = q.ravel()
+        nsym = int(counts.sum()) if bits[p] else 0  # an empty stream decodes to nothing (flat pictures)
+        nsym = min(nsym, flat.size)
+        sl = np.array([len_of[v] for v in flat[:nsym].tolist()], np.int64)
+        starts = np.concatenate([[0], np.cumsum(sl)[:-1]]) if nsym else np.zeros(0, np.int64)
+        assert (int(sl.sum()) if nsym else 0) == bits[p]
+        nent = (bits[p] + IDX_SUB_BITS - 1) // IDX_SUB_BITS
+        first = np.full(nent, nsym, np.uint32)
+        off = np.full(nent, 255, np.uint8)
+        for e in range(nent):
+            i = int(np.searchsorted(starts, e * IDX_SUB_BITS, side="left"))
+            if i < nsym and starts[i] < (e + 1) * IDX_SUB_BITS:
+                first[e] = i
+                off[e] = starts[i] - e * IDX_SUB_BITS
+        firsts.append(first); offs.append(off); nsyms.append(nsym); nents.append(nent)
+    ne = sum(nents)
+    head = struct.pack("<18I", 0x3249484B, 1, IDX_SUB_BITS, hd.h, hd.w, hd.lvl, bits[0], 0, bits[1], 0, bits[2], 0,
+                       *nsyms, *nents)
+    body = b"".join(f.astype("<u4").tobytes() for f in firsts) + b"".join(o.tobytes() for o in offs)
+    body += b"\0" * ((4 - ne % 4) % 4)
+    total = len(head) + len(body) + 8
+    gap = b"\0" * ((8 - len(comp) % 8) % 8)
+    return gap + head + body + struct.pack("<II", total, 0x4B484932)

@@ -14,6 +14,7 @@
 #include "khg_dec_plan.h"
 #include "khg_synth.h"
 #include "khg_visual.h"
+#include "khg_index.h"
 
 #ifndef KHG_SIM_SLACK
 #define KHG_SIM_SLACK 64  // bytes past each workspace array; 0 under AddressSanitizer to expose any overrun
@@ -99,8 +100,16 @@ static void sim_pack_single_pass(const KhgEncArgs& e) {
     delete ssh;
 }
 
+// format 2 (khg_ctx_set_format): the seek index behind the file
+static void sim_append_index(const KhgEncArgs& e) {
+    KhgIdxSmem* ish = new KhgIdxSmem;
+    for (uint32_t t = 0; t < e.chain_entries; ++t) khg_index_body(e, t, *ish);
+    delete ish;
+    khg_index_meta_body(e);
+}
+
 static int sim_encode(SimWs& S, const uint8_t* r, const uint8_t* g, const uint8_t* b, int rows, int cols, int lvl,
-                      uint8_t* out, size_t cap, size_t* out_len, int bgr_stride = 0) {
+                      uint8_t* out, size_t cap, size_t* out_len, int bgr_stride = 0, int format = 1) {
     forward_all(S, r, g, b, rows, cols, lvl, nullptr, KhgTile{0, 1}, bgr_stride);
     KhgTableArgs t = khg_table_args(S.ws);
     KhgTableSmem* tsh = new KhgTableSmem;
@@ -108,8 +117,16 @@ static int sim_encode(SimWs& S, const uint8_t* r, const uint8_t* g, const uint8_
     delete tsh;
     KhgEncArgs e = khg_enc_args(S.ws, rows, cols, lvl, out, cap);
     sim_pack_single_pass(e);
+    if (format == 2) sim_append_index(e);
     if (out_len) *out_len = (size_t)S.ws.res->total_len;
     return S.ws.res->status;
+}
+
+int khgsim_encode_indexed(const uint8_t* r, const uint8_t* g, const uint8_t* b, int rows, int cols, int lvl,
+                          uint8_t* out, size_t cap, size_t* out_len) {
+    if (!khg_dims_ok(rows, cols) || lvl < 0 || lvl > 2) return -1;
+    SimWs S(rows, cols);
+    return sim_encode(S, r, g, b, rows, cols, lvl, out, cap, out_len, 0, 2);
 }
 
 // the pixel array of a 24-bit BMP (B, G, R per pixel, rows bottom-up, `stride` bytes per row)
@@ -154,7 +171,7 @@ static void sim_inverse(SimWs& S, int rows, int cols, uint8_t* r, uint8_t* g, ui
 
 static int sim_decode(SimWs& S, const uint8_t* comp, size_t len, int rows, int cols, uint8_t* r, uint8_t* g, uint8_t* b,
                       int16_t* qy, int16_t* qcb, int16_t* qcr, int* passes_used, KhgTile tile,
-                      double* const ycbcr[3] = nullptr, size_t bgr_stride = 0) {
+                      double* const ycbcr[3] = nullptr, size_t bgr_stride = 0, bool indexed = false) {
     std::vector<uint8_t> buf((len + 3) & ~(size_t)3, 0);
     memcpy(buf.data(), comp, len);
     KhgDecArgs d = khg_dec_args(S.ws, S.dws, buf.data(), len, rows, cols);
@@ -167,9 +184,13 @@ static int sim_decode(SimWs& S, const uint8_t* comp, size_t len, int rows, int c
     KhgDecSmem<KHG_MAXOFF>* lsh2 = new KhgDecSmem<KHG_MAXOFF>;
     KhgDecWriteSmem* wsh = new KhgDecWriteSmem;
     KhgDecChainSmem* ssh = new KhgDecChainSmem;
-    for (uint32_t b_ = 0; b_ < d.nblocks; ++b_) khg_dec_map_body<KHG_MAP_SMALL>(d, b_, *lsh);
-    for (uint32_t b_ = 0; b_ < d.nblocks; ++b_) khg_dec_map_body<KHG_MAXOFF>(d, b_, *lsh2);
-    for (int p = 0; p < 3; ++p) khg_dec_chain_body(d, p, *ssh);
+    if (indexed) {
+        for (uint32_t b_ = 0; b_ < d.nblocks + 3; ++b_) khg_dec_index_body(d, b_);
+    } else {
+        for (uint32_t b_ = 0; b_ < d.nblocks; ++b_) khg_dec_map_body<KHG_MAP_SMALL>(d, b_, *lsh);
+        for (uint32_t b_ = 0; b_ < d.nblocks; ++b_) khg_dec_map_body<KHG_MAXOFF>(d, b_, *lsh2);
+        for (int p = 0; p < 3; ++p) khg_dec_chain_body(d, p, *ssh);
+    }
     if (passes_used) *passes_used = 1;
     for (uint32_t b_ = 0; b_ < d.nblocks; ++b_) khg_dec_write_body(d, b_, *wsh);
     delete lsh;
@@ -189,6 +210,17 @@ int khgsim_decode(const uint8_t* comp, size_t len, int rows, int cols, uint8_t* 
     if (!khg_dims_ok(rows, cols)) return -1;
     SimWs S(rows, cols);
     return sim_decode(S, comp, len, rows, cols, r, g, b, qy, qcb, qcr, passes_used, KhgTile{0, 1});
+}
+
+// Mirrors khg_decode_indexed_dev.  poison: the workspace is filled with it first (what another job left behind).
+int khgsim_decode_indexed(const uint8_t* comp, size_t len, int rows, int cols, uint8_t* r, uint8_t* g, uint8_t* b,
+                          int poison) {
+    if (!khg_dims_ok(rows, cols)) return -1;
+    SimWs S(rows, cols);
+    if (poison >= 0)
+        for (auto& buf : S.bufs) memset(buf.data(), poison, buf.size() - KHG_SIM_SLACK);
+    return sim_decode(S, comp, len, rows, cols, r, g, b, nullptr, nullptr, nullptr, nullptr, KhgTile{0, 1}, nullptr, 0,
+                      true);
 }
 
 // Mirrors khg_decode_bgr_dev: the picture as a BMP pixel array of `stride` bytes per row.

@@ -37,6 +37,9 @@ def lib():
         L.khgsim_decode_bgr.argtypes = [_u8p, C.c_size_t, C.c_int, C.c_int, _u8p, C.c_size_t]
         L.khgsim_ssim.argtypes = [_u8p, _u8p, C.c_int, C.c_int, C.c_void_p]
         L.khgsim_ssim.restype = C.c_double
+        L.khgsim_encode_indexed.argtypes = [_u8p, _u8p, _u8p, C.c_int, C.c_int, C.c_int, _u8p, C.c_size_t,
+                                            C.POINTER(C.c_size_t)]
+        L.khgsim_decode_indexed.argtypes = [_u8p, C.c_size_t, C.c_int, C.c_int, _u8p, _u8p, _u8p, C.c_int]
         L.khgsim_vis_coeffs.argtypes = [_u8p, _u8p, _u8p, C.c_int, C.c_int, _u8p, _u8p, _u8p]
         L.khgsim_vis_dequant.argtypes = [_u8p, C.c_size_t, C.c_int, C.c_int, _u8p, _u8p, _u8p]
         L.khgsim_vis_steps.argtypes = [C.c_int, C.c_int, C.c_int, _u8p, _u8p, _u8p, C.c_void_p]
@@ -156,6 +159,23 @@ def decode_bgr(comp, rows, cols, stride=None, fill=0x5C):
 def ssim(a, b):
     a = np.ascontiguousarray(a, np.uint8); b = np.ascontiguousarray(b, np.uint8)
     return lib().khgsim_ssim(a, b, a.shape[1], a.shape[0], None)
+
+
+def encode_indexed(rgb, lvl):
+    """Format 2: the format-1 file followed by its seek index."""
+    _, h, w = rgb.shape
+    cap = (36 + h * w * 3 + 3 * 16384 * 8 + 3) // 4 * 4 + 4096 + h * w
+    out = np.zeros(cap, np.uint8)
+    n = C.c_size_t(0)
+    rc = lib().khgsim_encode_indexed(rgb[0], rgb[1], rgb[2], h, w, lvl, out, cap, C.byref(n))
+    return rc, out[:n.value].tobytes() if rc == 0 else b""
+
+
+def decode_indexed(comp, rows, cols, poison=0xA5):
+    buf = np.frombuffer(comp, np.uint8).copy()
+    out = np.zeros((3, rows, cols), np.uint8)
+    rc = lib().khgsim_decode_indexed(buf, buf.size, rows, cols, out[0], out[1], out[2], poison)
+    return rc, out
 
 
 def vis_coeffs(rgb):

@@ -1,0 +1,162 @@
+"""Format 2: the reference's file followed by a seek index (csrc/khg_index.h).  It has no counterpart in the reference;
+what is checked is that the format-1 bytes in front are untouched (the reference's reader stops there), that the index
+is what its definition says (oracle_py.index_trailer derives it from a cumulative sum of code lengths), and that the
+indexed decoder produces the pixels of the ordinary one."""
+import struct
+
+import numpy as np
+import pytest
+
+import oracle_py as O
+import simlib as S
+from khugle_amd import synth_frame
+
+SHAPES = [(8, 8), (16, 24), (64, 72), (264, 520), (256, 136), (1024, 512)]
+
+
+def stress_frames():
+    from craft import stress_images
+    return stress_images(72, 136)
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("lvl", [0, 1, 2])
+def test_index_bytes_and_indexed_decode(shape, lvl):
+    rgb = synth_frame(shape[0], shape[1], 9, lvl)
+    v1 = O.encode(rgb, lvl)
+    rc, v2 = S.encode_indexed(rgb, lvl)
+    assert rc == 0
+    assert v2[:len(v1)] == v1                      # what ReadAll reads is unchanged
+    assert v2[len(v1):] == O.index_trailer(v1)     # the index is what its definition says
+    assert O.decode(v2[:len(v1)]).shape == rgb.shape
+    rc, out = S.decode_indexed(v2, shape[0], shape[1])
+    assert rc == 0 and np.array_equal(out, O.decode(v1))
+    rc, out, _, _ = S.decode(v2, shape[0], shape[1])  # the ordinary decoder ignores the index
+    assert rc == 0 and np.array_equal(out, O.decode(v1))
+
+
+def test_pictures_at_the_corners_of_the_format():
+    """Flat colour (empty streams, no entries), white noise (long codes), and the other stress pictures."""
+    for name, rgb in stress_frames().items():
+        for lvl in (0, 2):
+            v1 = O.encode(rgb, lvl)
+            rc, v2 = S.encode_indexed(rgb, lvl)
+            assert rc == 0 and v2[:len(v1)] == v1 and v2[len(v1):] == O.index_trailer(v1), name
+            rc, out = S.decode_indexed(v2, rgb.shape[1], rgb.shape[2])
+            assert rc == 0 and np.array_equal(out, O.decode(v1)), name
+
+
+def test_files_without_a_sound_index_are_refused():
+    rgb = synth_frame(64, 72, 3, 1)
+    v1 = O.encode(rgb, 1)
+    rc, v2 = S.encode_indexed(rgb, 1)
+    assert rc == 0
+    assert S.decode_indexed(v1, 64, 72)[0] == -3                 # no index at all
+    begin = (len(v1) + 7) // 8 * 8
+    for pos, val in [(begin, 0x00), (begin + 4, 0x09), (begin + 8, 0x80), (begin + 12, 0x48), (begin + 24, 0x01),
+                     (begin + 60, 0x7F), (len(v2) - 1, 0x00), (len(v2) - 8, 0x01)]:
+        bad = bytearray(v2)
+        bad[pos] ^= val or 0xFF
+        assert S.decode_indexed(bytes(bad), 64, 72)[0] == -3, pos
+    assert S.decode_indexed(v2[:-4], 64, 72)[0] == -3             # cut short
+
+
+def test_an_index_that_lies_cannot_reach_outside_the_buffers():
+    """Random damage to the entries of a sound index: wrong pixels at worst (run under AddressSanitizer by
+    tools/asan_sim.sh, with the workspace sized exactly)."""
+    rgb = synth_frame(136, 264, 4, 1)
+    v1 = O.encode(rgb, 1)
+    rc, v2 = S.encode_indexed(rgb, 1)
+    assert rc == 0
+    begin = (len(v1) + 7) // 8 * 8 + 72
+    rng = np.random.default_rng(5)
+    for rep in range(40):
+        bad = bytearray(v2)
+        for _ in range(int(rng.integers(1, 30))):
+            bad[int(rng.integers(begin, len(v2) - 8))] = int(rng.integers(0, 256))
+        rc, out = S.decode_indexed(bytes(bad), 136, 264)
+        assert rc in (0, -3)
+
+
+# ------------------------------------------------------------------ on the GPU, through the C ABI
+def _gpu_encode_indexed(codec, rgb, lvl):
+    import torch
+    _, h, w = rgb.shape
+    d = torch.from_numpy(rgb).cuda()
+    out = torch.zeros(codec.comp_bound(h, w) + codec.index_bound(h, w), dtype=torch.uint8, device="cuda")
+    codec.set_format(2)
+    try:
+        codec.encode_dev(d, lvl, out)
+        n = codec.encode_result()
+    finally:
+        codec.set_format(1)
+    return out, n
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", SHAPES + [(2160, 3840)])
+def test_gpu_index(codec, shape):
+    import torch
+    h, w = shape
+    rgb = synth_frame(h, w, 9, 1)
+    v1 = codec.encode(rgb, 1)
+    out, n = _gpu_encode_indexed(codec, rgb, 1)
+    v2 = out[:n].cpu().numpy().tobytes()
+    assert v2[:len(v1)] == v1
+    if h * w <= 1 << 20:
+        assert v1 == O.encode(rgb, 1) and v2[len(v1):] == O.index_trailer(v1)
+    else:
+        assert v2 == S.encode_indexed(rgb, 1)[1]
+    codec.debug_poison(0xA5)
+    dec = torch.zeros((3, h, w), dtype=torch.uint8, device="cuda")
+    codec.decode_indexed_dev(out, n, h, w, dec)
+    assert codec.last_status() == 0
+    assert np.array_equal(dec.cpu().numpy(), codec.decode(v1))
+    assert np.array_equal(codec.decode(v2), codec.decode(v1))  # the ordinary decoder ignores the index
+    # a file without an index, a damaged one, and a buffer too small for the index
+    from khugle_amd.lib import ERR_CAP, ERR_FORMAT
+    pad = np.zeros((len(v1) + 3) // 4 * 4, np.uint8)
+    pad[:len(v1)] = np.frombuffer(v1, np.uint8)
+    codec.decode_indexed_dev(torch.from_numpy(pad).cuda(), len(v1), h, w, dec)
+    assert codec.last_status() == ERR_FORMAT
+    bad = out.clone()
+    bad[(len(v1) + 7) // 8 * 8 + 4] ^= 0x7F
+    codec.decode_indexed_dev(bad, n, h, w, dec)
+    assert codec.last_status() == ERR_FORMAT
+    small = torch.zeros((len(v1) + 3) // 4 * 4 + 64, dtype=torch.uint8, device="cuda")
+    codec.set_format(2)
+    try:
+        codec.encode_dev(torch.from_numpy(rgb).cuda(), 1, small)
+        with pytest.raises(Exception) as e:
+            codec.encode_result()
+        assert e.value.code == ERR_CAP
+    finally:
+        codec.set_format(1)
+
+
+@pytest.mark.gpu
+def test_gpu_index_full_frame_and_stress():
+    """An 8K frame: same pixels with and without the index; the stress pictures through both decoders."""
+    import torch
+    from khugle_amd import Codec
+    codec = Codec(4320, 7680)
+    rgb = codec.synth_dev(4320, 7680, 2025, 3).cpu().numpy()
+    v1 = codec.encode(rgb, 1)
+    out, n = _gpu_encode_indexed(codec, rgb, 1)
+    assert out[:len(v1)].cpu().numpy().tobytes() == v1
+    dec = torch.zeros((3, 4320, 7680), dtype=torch.uint8, device="cuda")
+    codec.decode_indexed_dev(out, n, 4320, 7680, dec)
+    assert codec.last_status() == 0
+    want = torch.zeros_like(dec)
+    codec.decode_dev(out, len(v1), 4320, 7680, want)
+    assert codec.last_status() == 0
+    assert torch.equal(dec, want)
+    for name, pic in stress_frames().items():
+        v1 = codec.encode(pic, 2)
+        out, n = _gpu_encode_indexed(codec, pic, 2)
+        v2 = out[:n].cpu().numpy().tobytes()
+        assert v2[:len(v1)] == v1 and v2[len(v1):] == O.index_trailer(v1), name
+        dec = torch.zeros((3,) + pic.shape[1:], dtype=torch.uint8, device="cuda")
+        codec.decode_indexed_dev(out, n, pic.shape[1], pic.shape[2], dec)
+        assert codec.last_status() == 0 and np.array_equal(dec.cpu().numpy(), O.decode(v1)), name
+    codec.close()

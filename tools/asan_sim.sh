@@ -15,7 +15,7 @@ import simlib as S
 S.SO = "$SO"
 S.build = lambda force=False: None
 import pytest
-sys.exit(pytest.main(["$ROOT/tests/test_sim_kernels.py", "$ROOT/tests/test_tiled.py", "$ROOT/tests/test_ordered_sum.py", "-x", "-q", "-k", "not gloo and not every_rank and not gpu",
+sys.exit(pytest.main(["$ROOT/tests/test_sim_kernels.py", "$ROOT/tests/test_tiled.py", "$ROOT/tests/test_ordered_sum.py", "$ROOT/tests/test_index.py", "$ROOT/tests/test_visual.py", "-x", "-q", "-k", "not gloo and not every_rank and not gpu",
                       "-p", "no:cacheprovider"]))
 PY
 ASAN_OPTIONS=detect_leaks=0 LD_PRELOAD=$(g++ -print-file-name=libasan.so)${LD_PRELOAD:+:$LD_PRELOAD} python /tmp/run_asan_suite.py
