@@ -111,6 +111,7 @@ def main():
     ap.add_argument("--cols", type=int, default=COLS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-square", action="store_true", help="skip the short 5760x5760 pass")
+    ap.add_argument("--no-format2", action="store_true", help="skip the short pass with the opt-in seek index")
     ap.add_argument("--no-host-pipeline", action="store_true", help="skip the short pass over frames in host memory")
     ap.add_argument("--no-isolated-kernel", action="store_true",
                     help="skip timing the dominant kernel alone on an idle GPU (20 launches after the timed region)")
@@ -262,6 +263,56 @@ def main():
                   "value": round(whole_job_rate(world, SF, 1, side * side, st), 1), "unit": "MP/s"}
         del sctx, sfr, scomp, sdec
 
+    # the same frames in the opt-in format 2 (the format-1 file followed by a seek index, csrc/khg_index.h): one pass
+    # each way.  Never part of `value`: the headline is the reference's own format.
+    format2 = None
+    dec_last = decs[(F - 1) % S].clone()  # the timed decode's picture of the last frame, for the parity spot check
+    if not args.no_format2:
+        lens2 = [0] * F
+
+        def encode2_pass():
+            for f in range(F):
+                c = f % S
+                if f >= S:
+                    lens2[f - S] = ctxs[c].encode_result()
+                with torch.cuda.stream(streams[c]):
+                    ctxs[c].encode_dev(frames[f], LVL, comps[f])
+            for f in range(max(0, F - S), F):
+                lens2[f] = ctxs[f % S].encode_result()
+
+        def decode2_pass():
+            for f in range(F):
+                c = f % S
+                if f >= S and ctxs[c].last_status() != 0:
+                    raise RuntimeError("indexed decode failed")
+                with torch.cuda.stream(streams[c]):
+                    ctxs[c].decode_indexed_dev(comps[f], lens2[f], rows, cols, decs[c])
+            for c in range(S):
+                if ctxs[c].last_status() != 0:
+                    raise RuntimeError("indexed decode failed")
+
+        for c in ctxs:
+            c.set_format(2)
+        encode2_pass(); decode2_pass()
+        barrier()
+        a2 = time.perf_counter()
+        encode2_pass()
+        torch.cuda.synchronize()
+        b2 = time.perf_counter()
+        decode2_pass()
+        torch.cuda.synchronize()
+        c2 = time.perf_counter()
+        barrier()
+        for c in ctxs:
+            c.set_format(1)
+        e2, d2 = max_over_ranks([b2 - a2, c2 - b2], dev)
+        format2 = {"what": "the format-1 file followed by a seek index (opt-in, no counterpart in the reference); "
+                           "one pass each way over the same frames and streams",
+                   "encode_mp_s": round(whole_job_rate(world, F, 1, px, e2), 1),
+                   "decode_mp_s": round(whole_job_rate(world, F, 1, px, d2), 1),
+                   "bytes_per_frame": int(sum(lens2) / F), "format1_bytes_per_frame": int(sum(lens) / F),
+                   "same_pixels_as_format1": bool(torch.equal(decs[(F - 1) % S], dec_last))}
+
     # frames and files in (pinned) host memory through the library's pipelined batch entry points: the rate a host
     # application sees, PCIe copies included.  Never part of `value`.
     host = None
@@ -306,7 +357,7 @@ def main():
             rgb = frames[f].cpu().numpy()
             comp = comps[f, :lens[f]].cpu().numpy().tobytes()
             want = O.encode(rgb, LVL)
-            dec = decs[f % S].cpu().numpy()
+            dec = dec_last.cpu().numpy()
             parity = bool(comp == want) and bool(np.array_equal(dec, O.decode(want)))
         except Exception as e:  # the oracle is test infrastructure: never let it break the measurement
             parity = "unavailable: %s" % e
@@ -384,6 +435,7 @@ def main():
                                "decode_gbps": round((63 + bpp / 8) * total_mp / t_dec / 1e3, 1),
                                "peak_gbps": HBM_PEAK_GBS * world},
             "square_variant": square,
+            "format2": format2,
             "host_pipeline": host,
         }
         print(json.dumps(line), flush=True)
