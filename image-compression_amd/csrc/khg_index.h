@@ -154,27 +154,25 @@ KHG_DEV void khg_index_body(const KhgEncArgs& a, uint32_t t, KhgIdxSmem& sh)
     }
 }
 
-// The index's fixed words and the file's new length.  One workgroup of 256 threads, after khg_index_body.
+// The index's fixed words and the file's new length.  One thread (of a workgroup of 64), after khg_index_body.
 KHG_DEV void khg_index_meta_body(const KhgEncArgs& a)
 {
-    if (a.res->status != 0 || !a.res->ok_to_pack) return;
-    const uint64_t v1_len = a.res->total_len;
-    const KhgIdxPlace pl = khg_idx_place(a, v1_len);
-    KHG_FOR_THREADS(256)
+    KHG_FOR_THREADS(64)
     {
-        if (!pl.fits) {
-            if (tid == 0) khg_set_status(&a.res->status, -2);
-        } else {
-            uint8_t* o = a.out + pl.begin;
-            const uint32_t ne = pl.entries[0] + pl.entries[1] + pl.entries[2];
-            if (tid == 0) {
+        if (tid == 0 && a.res->status == 0 && a.res->ok_to_pack) {
+            const uint64_t v1_len = a.res->total_len;
+            const KhgIdxPlace pl = khg_idx_place(a, v1_len);
+            if (!pl.fits) {
+                khg_set_status(&a.res->status, -2);
+            } else {
+                uint8_t* o = a.out + pl.begin;
+                const uint32_t ne = pl.entries[0] + pl.entries[1] + pl.entries[2];
                 for (uint64_t i = v1_len; i < pl.begin; ++i) a.out[i] = 0;
                 const uint32_t w[KHG_IDX_HEAD_WORDS] = {
                     (uint32_t)KHG_IDX_MAGIC, KHG_IDX_VERSION, KHG_SUB_BITS, (uint32_t)a.rows, (uint32_t)a.cols, (uint32_t)a.lvl,
                     (uint32_t)pl.bits[0], (uint32_t)(pl.bits[0] >> 32), (uint32_t)pl.bits[1], (uint32_t)(pl.bits[1] >> 32),
                     (uint32_t)pl.bits[2], (uint32_t)(pl.bits[2] >> 32), pl.bits[0] ? a.n[0] : 0u, pl.bits[1] ? a.n[1] : 0u,
-                    pl.bits[2] ? a.n[2] : 0u,
-                    pl.entries[0], pl.entries[1], pl.entries[2]};
+                    pl.bits[2] ? a.n[2] : 0u, pl.entries[0], pl.entries[1], pl.entries[2]};
                 for (int i = 0; i < KHG_IDX_HEAD_WORDS; ++i) khg_idx_store32(o + 4 * i, w[i]);
                 uint8_t* tail = o + 4 * KHG_IDX_HEAD_WORDS + 4 * (size_t)ne;
                 for (uint32_t i = ne; i < ((ne + 3) & ~3u); ++i) tail[i] = 0;

@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void khg_index_kernel(KhgEncArgs a)
     __shared__ KhgIdxSmem sh;
     khg_index_body(a, blockIdx.x, sh);
 }
-__global__ __launch_bounds__(256) void khg_index_meta_kernel(KhgEncArgs a) { khg_index_meta_body(a); }
+__global__ __launch_bounds__(64) void khg_index_meta_kernel(KhgEncArgs a) { khg_index_meta_body(a); }
 // Workgroups in the write launch's order, then one per plane.
 __global__ __launch_bounds__(256) void khg_dec_index_kernel(KhgDecArgs a, uint32_t nwrite)
 {
@@ -431,7 +431,7 @@ static int khg_enqueue_entropy(khg_ctx* c, int rows, int cols, int lvl, uint8_t*
     hipLaunchKernelGGL(khg_meta_kernel, dim3(1), dim3(1024), 0, st, e);
     if (c->format == 2) {  // the seek index behind the file (khg_index.h)
         hipLaunchKernelGGL(khg_index_kernel, dim3(e.chain_entries), dim3(256), 0, st, e);
-        hipLaunchKernelGGL(khg_index_meta_kernel, dim3(1), dim3(256), 0, st, e);
+        hipLaunchKernelGGL(khg_index_meta_kernel, dim3(1), dim3(64), 0, st, e);
     }
     KHG_HIP(hipGetLastError());
     KHG_HIP(hipMemcpyAsync(c->h_res, c->ws.res, sizeof(KhgResult), hipMemcpyDeviceToHost, st));

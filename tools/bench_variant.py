@@ -13,7 +13,7 @@ import io
 import contextlib
 import bench
 
-sys.argv = ["bench.py", "--no-cpu-baseline", "--no-square", "--no-host-pipeline", "--no-isolated-kernel"] + sys.argv[1:]
+sys.argv = ["bench.py", "--no-cpu-baseline", "--no-square", "--no-host-pipeline", "--no-isolated-kernel", "--no-format2"] + sys.argv[1:]
 buf = io.StringIO()
 with contextlib.redirect_stdout(buf):
     bench.main()
