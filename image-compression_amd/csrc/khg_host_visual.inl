@@ -80,3 +80,19 @@ extern "C" int khg_vis_dequant_dev(khg_ctx* c, const uint8_t* d_comp, size_t len
     if (!d_or || !d_og || !d_ob) return KHG_ERR_ARG;
     return khg_decode_enqueue(c, d_comp, len, rows, cols, d_or, d_og, d_ob, stream, KhgTile{0, 1}, nullptr, 0, true);
 }
+
+extern "C" int khg_downsample_dev(const uint8_t* d_src, int src_rows, int src_cols, uint8_t* d_dst, int dst_rows, int dst_cols,
+                                  void* stream)
+{
+    if (!d_src || !d_dst) return KHG_ERR_ARG;
+    if (src_rows < 1 || src_cols < 1 || dst_rows < 1 || dst_cols < 1) return KHG_ERR_DIMS;
+    // single-precision positions: (dst - 1) * (src / dst) stays below src only while 1 / dst is well above the
+    // rounding error, so sides are limited to 2^22 (the application asks for 256)
+    if (src_rows > (1 << 22) || src_cols > (1 << 22) || dst_rows > (1 << 22) || dst_cols > (1 << 22)) return KHG_ERR_DIMS;
+    KhgDownArgs a;
+    a.src = d_src; a.src_h = src_rows; a.src_w = src_cols;
+    a.dst = d_dst; a.dst_h = dst_rows; a.dst_w = dst_cols;
+    hipLaunchKernelGGL(khg_downsample_kernel, dim3(khg_vis_grid(dst_rows, dst_cols)), dim3(256), 0, (hipStream_t)stream, a);
+    KHG_HIP(hipGetLastError());
+    return KHG_OK;
+}

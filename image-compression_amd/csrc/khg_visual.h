@@ -143,3 +143,56 @@ KHG_DEV void khg_vis_bar_body(const KhgVisBarArgs& a, uint32_t bid)
         }
     }
 }
+
+// ---- the thumbnails the application draws its pictures as (DownSample.h:5-37, called for 256 x 256 from
+// Main.cpp:59-61): bilinear interpolation in single precision, operation for operation.  Where the reference divides
+// by zero (a sample position on the last row or column of the source: x2 == x1) its result is NaN or infinite and
+// the conversion to unsigned char is undefined; this does what the reference's x86-64 build does there
+// (cvttss2si gives INT_MIN, whose low byte is 0).
+struct KhgDownArgs {
+    const uint8_t* src;
+    int src_h, src_w;
+    uint8_t* dst;
+    int dst_h, dst_w;
+};
+
+// float -> unsigned char as the reference's build converts it: truncate to a 32-bit int (INT_MIN when that is
+// impossible), keep the low byte.
+KHG_DEV uint8_t khg_f32_to_u8(float v)
+{
+    if (!(v > -2147483904.0f && v < 2147483648.0f)) return 0;  // NaN, infinities, out of int range
+    return (uint8_t)(uint32_t)(int32_t)v;
+}
+
+#ifdef KHG_SIM
+KHG_DEV float khg_div_f32(float a, float b) { return a / b; }
+#else
+KHG_DEV float khg_div_f32(float a, float b) { return __fdiv_rn(a, b); }  // correctly rounded, whatever the build's default
+#endif
+
+KHG_DEV void khg_downsample_body(const KhgDownArgs& a, uint32_t bid)
+{
+    KHG_FOR_THREADS(256)
+    {
+        const size_t p = (size_t)bid * 256 + (size_t)tid;
+        if (p < (size_t)a.dst_h * (size_t)a.dst_w) {
+            const int yy = (int)(p / (size_t)a.dst_w), xx = (int)(p - (size_t)yy * (size_t)a.dst_w);
+            const float scaleX = (float)a.src_w / (float)a.dst_w, scaleY = (float)a.src_h / (float)a.dst_h;  // DownSample.h:29-30
+            const float x = (float)xx * scaleX, y = (float)yy * scaleY;                                  // :34
+            int x1 = (int)__builtin_floorf(x), y1 = (int)__builtin_floorf(y);                            // :7-8
+            x1 = x1 < a.src_w - 1 ? x1 : a.src_w - 1;  // never taken for the sizes the entry point accepts; keeps every
+            y1 = y1 < a.src_h - 1 ? y1 : a.src_h - 1;  // load inside the plane regardless
+            const int x2 = x1 + 1 < a.src_w - 1 ? x1 + 1 : a.src_w - 1;                                  // :9-10
+            const int y2 = y1 + 1 < a.src_h - 1 ? y1 + 1 : a.src_h - 1;
+            const float Q11 = (float)a.src[(size_t)y1 * a.src_w + x1], Q21 = (float)a.src[(size_t)y1 * a.src_w + x2];
+            const float Q12 = (float)a.src[(size_t)y2 * a.src_w + x1], Q22 = (float)a.src[(size_t)y2 * a.src_w + x2];
+            const float dx = (float)(x2 - x1), dy = (float)(y2 - y1);
+            const float wx2 = khg_div_f32((float)x2 - x, dx), wx1 = khg_div_f32(x - (float)x1, dx);
+            const float wy2 = khg_div_f32((float)y2 - y, dy), wy1 = khg_div_f32(y - (float)y1, dy);
+            const float R1 = wx2 * Q11 + wx1 * Q21;  // :17
+            const float R2 = wx2 * Q12 + wx1 * Q22;  // :18
+            const float P = wy2 * R1 + wy1 * R2;     // :20
+            a.dst[p] = khg_f32_to_u8(P);
+        }
+    }
+}

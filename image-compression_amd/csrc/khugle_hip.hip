@@ -165,6 +165,7 @@ __global__ __launch_bounds__(256) void khg_dec_index_kernel(KhgDecArgs a, uint32
 __global__ __launch_bounds__(256) void khg_vis_ycc_kernel(KhgVisYccArgs a) { khg_vis_ycc_body(a, blockIdx.x); }
 __global__ __launch_bounds__(256) void khg_vis_step_kernel(KhgVisStepArgs a) { khg_vis_step_body(a, blockIdx.x); }
 __global__ __launch_bounds__(256) void khg_vis_bar_kernel(KhgVisBarArgs a) { khg_vis_bar_body(a, blockIdx.x); }
+__global__ __launch_bounds__(256) void khg_downsample_kernel(KhgDownArgs a) { khg_downsample_body(a, blockIdx.x); }
 
 __global__ __launch_bounds__(256) void khg_ssim_kernel(KhgSsimArgs a)
 {

@@ -149,6 +149,14 @@ class Codec:
                "vis_bars_dev")
         return out
 
+    def downsample_dev(self, plane, dst_rows=256, dst_cols=256):
+        """DownSampleImage (DownSample.h:25-37) of one (H, W) uint8 cuda plane."""
+        assert plane.is_cuda and plane.dtype == self.torch.uint8 and plane.is_contiguous() and plane.dim() == 2
+        out = self.torch.empty((dst_rows, dst_cols), dtype=self.torch.uint8, device=plane.device)
+        _check(self.L.khg_downsample_dev(_ptr(plane), plane.shape[0], plane.shape[1], _ptr(out), dst_rows, dst_cols,
+                                         _stream()), "downsample_dev")
+        return out
+
     def last_status(self):
         return self.L.khg_last_status(self._ctx)
 

@@ -49,6 +49,7 @@ SYMBOLS = [
     ("khg_vis_dequant_dev", C.c_int, [_P, _P, C.c_size_t, C.c_int, C.c_int, _P, _P, _P, _P]),
     ("khg_vis_steps_dev", C.c_int, [C.c_int, C.c_int, C.c_int, _P, _P, _P, _P]),
     ("khg_vis_bars_dev", C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_longlong), _P, _P, _P, _P]),
+    ("khg_downsample_dev", C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int, C.c_int, _P]),
     ("khg_ordered_mean_dev", C.c_int, [_P, C.c_size_t, _P, _P]),
     ("khg_decode_bgr_dev", C.c_int, [_P, _P, C.c_size_t, C.c_int, C.c_int, _P, C.c_size_t, _P]),
     ("khg_encode_bgr_dev", C.c_int, [_P, _P, C.c_size_t, C.c_int, C.c_int, C.c_int, _P, C.c_size_t, _P]),

@@ -168,6 +168,12 @@ int khg_vis_dequant_dev(khg_ctx *ctx, const uint8_t *d_comp, size_t len, int row
 int khg_vis_steps_dev(int rows, int cols, int lvl, uint8_t *d_out_r, uint8_t *d_out_g, uint8_t *d_out_b, void *stream);
 int khg_vis_bars_dev(int rows, int cols, const long long *len_bytes, uint8_t *d_out_r, uint8_t *d_out_g,
                      uint8_t *d_out_b, void *stream);
+/* DownSampleImage (DownSample.h:5-37; the application draws every picture as a 256 x 256 thumbnail, Main.cpp:59-61):
+ * one plane, bilinear interpolation in single precision, operation for operation.  Where the reference divides by zero
+ * (sample positions on the source's last row or column) and then converts NaN to unsigned char, the value is 0, as in
+ * the reference's x86-64 build.  Sides up to 2^22.  Asynchronous, no context. */
+int khg_downsample_dev(const uint8_t *d_src, int src_rows, int src_cols, uint8_t *d_dst, int dst_rows, int dst_cols,
+                       void *stream);
 
 /* ---- an entry point that allocates nothing.  It has no counterpart in the reference: it exists for callers that
  * cannot allocate device or pinned memory -- code under HIP graph capture, tight serving loops, harnesses that

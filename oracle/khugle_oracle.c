@@ -848,3 +848,33 @@ int khgo_vis_bars(int h, int w, const long long *len, uint8_t *r, uint8_t *g, ui
     }
     return 0;
 }
+
+/* DownSample.h:5-37: bilinear thumbnail of one plane, single precision.  The unsigned char conversion of a NaN or an
+ * infinity (division by zero on the source's last row / column) is undefined in C; the reference's x86-64 build
+ * yields 0 there (cvttss2si -> INT_MIN, low byte), and so does this restatement. */
+static unsigned char khgo_f32_to_u8(float v)
+{
+    if (!(v > -2147483904.0f && v < 2147483648.0f)) return 0;
+    return (unsigned char)(unsigned int)(int)v;
+}
+
+int khgo_downsample(const uint8_t *src, int srcHeight, int srcWidth, uint8_t *dst, int dstHeight, int dstWidth)
+{
+    const float scaleX = (float)srcWidth / (float)dstWidth;   /* DownSample.h:29 */
+    const float scaleY = (float)srcHeight / (float)dstHeight; /* DownSample.h:30 */
+    for (int yy = 0; yy < dstHeight; ++yy)
+        for (int xx = 0; xx < dstWidth; ++xx) {
+            volatile float x = xx * scaleX, y = yy * scaleY; /* DownSample.h:34 (float arguments) */
+            int x1 = (int)floor(x);                          /* DownSample.h:7 */
+            int y1 = (int)floor(y);
+            int x2 = KHGO_MIN(x1 + 1, srcWidth - 1);
+            int y2 = KHGO_MIN(y1 + 1, srcHeight - 1);
+            unsigned char Q11 = src[(size_t)y1 * srcWidth + x1], Q21 = src[(size_t)y1 * srcWidth + x2];
+            unsigned char Q12 = src[(size_t)y2 * srcWidth + x1], Q22 = src[(size_t)y2 * srcWidth + x2];
+            float R1 = ((x2 - x) / (x2 - x1)) * Q11 + ((x - x1) / (x2 - x1)) * Q21; /* DownSample.h:17 */
+            float R2 = ((x2 - x) / (x2 - x1)) * Q12 + ((x - x1) / (x2 - x1)) * Q22; /* DownSample.h:18 */
+            float P = ((y2 - y) / (y2 - y1)) * R1 + ((y - y1) / (y2 - y1)) * R2;    /* DownSample.h:20 */
+            dst[(size_t)yy * dstWidth + xx] = khgo_f32_to_u8(P);
+        }
+    return 0;
+}

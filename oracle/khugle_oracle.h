@@ -122,6 +122,8 @@ double khgo_psnr(const uint8_t *ir, const uint8_t *ig, const uint8_t *ib,
  * "RLE Size (Y, Cb, Cr) : ..." into str2 (100 bytes each, or NULL). */
 int khgo_vis_steps(int h, int w, int lvl, long k_y, long k_cb, long k_cr, uint8_t *r, uint8_t *g, uint8_t *b,
                    char *str, char *str2);
+/* DownSample.h:5-37: the thumbnail of one plane (NaN -> 0 where the reference divides by zero). */
+int khgo_downsample(const uint8_t *src, int srcHeight, int srcWidth, uint8_t *dst, int dstHeight, int dstWidth);
 /* Compress.h:330-391 / Decompress.h:128-188: the stream lengths (bytes) as bars. */
 int khgo_vis_bars(int h, int w, const long long *len, uint8_t *r, uint8_t *g, uint8_t *b);
 

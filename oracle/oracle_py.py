@@ -68,6 +68,7 @@ def lib():
         L.khgo_psnr.restype = C.c_double
         L.khgo_vis_steps.argtypes = [C.c_int, C.c_int, C.c_int, C.c_long, C.c_long, C.c_long, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_char_p, C.c_char_p]
+        L.khgo_downsample.argtypes = [_u8p, C.c_int, C.c_int, _u8p, C.c_int, C.c_int]
         L.khgo_vis_bars.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_longlong), _u8p, _u8p, _u8p]
         _lib = L
     return _lib
@@ -248,6 +249,13 @@ def vis_steps(h, w, lvl, tables=(0, 0, 0)):
     if rc:
         raise OracleError(rc)
     return out, s1.value.decode(), s2.value.decode()
+
+
+def downsample(plane, dst_h=256, dst_w=256):
+    plane = np.ascontiguousarray(plane, np.uint8)
+    out = np.zeros((dst_h, dst_w), np.uint8)
+    lib().khgo_downsample(plane, plane.shape[0], plane.shape[1], out, dst_h, dst_w)
+    return out
 
 
 def vis_bars(h, w, lens):

@@ -295,6 +295,14 @@ int khgsim_vis_bars(int rows, int cols, const long long* len, uint8_t* r, uint8_
     return 0;
 }
 
+int khgsim_downsample(const uint8_t* src, int sh_, int sw, uint8_t* dst, int dh, int dw) {
+    KhgDownArgs a;
+    a.src = src; a.src_h = sh_; a.src_w = sw; a.dst = dst; a.dst_h = dh; a.dst_w = dw;
+    const uint32_t nb = (uint32_t)(((size_t)dh * dw + 255) / 256);
+    for (uint32_t b_ = 0; b_ < nb; ++b_) khg_downsample_body(a, b_);
+    return 0;
+}
+
 // ---- one long-lived workspace, as a khg_ctx has: jobs of any size up to its maximum, one after another, and a
 // poison fill that stands for whatever an earlier job left behind (khg_debug_poison)
 struct SimCtx {

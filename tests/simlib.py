@@ -40,6 +40,7 @@ def lib():
         L.khgsim_encode_indexed.argtypes = [_u8p, _u8p, _u8p, C.c_int, C.c_int, C.c_int, _u8p, C.c_size_t,
                                             C.POINTER(C.c_size_t)]
         L.khgsim_decode_indexed.argtypes = [_u8p, C.c_size_t, C.c_int, C.c_int, _u8p, _u8p, _u8p, C.c_int]
+        L.khgsim_downsample.argtypes = [_u8p, C.c_int, C.c_int, _u8p, C.c_int, C.c_int]
         L.khgsim_vis_coeffs.argtypes = [_u8p, _u8p, _u8p, C.c_int, C.c_int, _u8p, _u8p, _u8p]
         L.khgsim_vis_dequant.argtypes = [_u8p, C.c_size_t, C.c_int, C.c_int, _u8p, _u8p, _u8p]
         L.khgsim_vis_steps.argtypes = [C.c_int, C.c_int, C.c_int, _u8p, _u8p, _u8p, C.c_void_p]
@@ -176,6 +177,13 @@ def decode_indexed(comp, rows, cols, poison=0xA5):
     out = np.zeros((3, rows, cols), np.uint8)
     rc = lib().khgsim_decode_indexed(buf, buf.size, rows, cols, out[0], out[1], out[2], poison)
     return rc, out
+
+
+def downsample(plane, dst_h=256, dst_w=256):
+    plane = np.ascontiguousarray(plane, np.uint8)
+    out = np.zeros((dst_h, dst_w), np.uint8)
+    lib().khgsim_downsample(plane, plane.shape[0], plane.shape[1], out, dst_h, dst_w)
+    return out
 
 
 def vis_coeffs(rgb):

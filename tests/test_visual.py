@@ -61,7 +61,32 @@ def test_coefficient_pictures(shape):
         assert rc == 0 and np.array_equal(got, O.vis_dequant(comp)), lvl
 
 
+DOWN_CASES = [((256, 256), (256, 256)), ((512, 512), (256, 256)), ((264, 520), (256, 256)), ((72, 136), (256, 256)),
+              ((1000, 1504), (256, 256)), ((64, 64), (7, 13)), ((8, 8), (1, 1)), ((300, 200), (299, 201))]
+
+
+@pytest.mark.parametrize("src,dst", DOWN_CASES)
+def test_thumbnails(src, dst):
+    """DownSampleImage (DownSample.h:5-37): the kernel body against the oracle's single-precision restatement,
+    including the sizes at which the reference divides by zero on the last row and column (equal sizes, enlargement)."""
+    rng = np.random.default_rng(src[0] * 7 + dst[1])
+    plane = rng.integers(0, 256, src, dtype=np.uint8)
+    assert np.array_equal(S.downsample(plane, *dst), O.downsample(plane, *dst))
+    smooth = synth_frame((src[0] + 7) // 8 * 8, (src[1] + 7) // 8 * 8, 3, 0)[0][:src[0], :src[1]]
+    assert np.array_equal(S.downsample(smooth, *dst), O.downsample(smooth, *dst))
+
+
 # ------------------------------------------------------------------ the same on the GPU, through the C ABI
+@pytest.mark.gpu
+@pytest.mark.parametrize("src,dst", DOWN_CASES + [((4320, 7680), (256, 256))])
+def test_gpu_thumbnails(codec, src, dst):
+    import torch
+    rng = np.random.default_rng(src[0] * 7 + dst[1])
+    plane = rng.integers(0, 256, src, dtype=np.uint8)
+    got = codec.downsample_dev(torch.from_numpy(plane).cuda(), *dst).cpu().numpy()
+    assert np.array_equal(got, O.downsample(plane, *dst))
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape", SHAPES + [(2160, 3840)])
 def test_gpu_pictures(codec, shape):
