@@ -75,13 +75,17 @@ struct KhgFwdArgs {
     // RGB launch: [0] = Y, [1] = Cb, [2] = Cr (Cb and Cr share one grid: a lane carries both).
     // Plane launches: up to three independent planes.
     KhgFwdPlane pl[3];
+    int lhist;                 // level 2: bins of the workgroup histogram in use (a power of two up to the capacity)
 };
 
 // LDS of one workgroup.  Level 1 emits detail bands only (small symbols, three bands): 256 bins.  Level 2 also emits
-// the LL band, whose symbols spread over hundreds of values: 1024 bins, four bands.
+// the LL band, whose symbols spread over hundreds of values and at the Normal preset (LL step 1.011) reach 1009: room
+// for 2048 bins (more would cost the fourth workgroup per CU that the launch plan counts on), of which a launch uses
+// KhgFwdArgs::lhist.  Symbols outside the bins go to the global histogram one atomic at a time, and neighbouring LL
+// symbols collide there: with 1024 bins the Normal preset's level 2 took 0.75 ms instead of 0.05.
 template <int LEVEL, int NP>
 struct KhgFwdSmem {
-    enum { LHIST = LEVEL == 1 ? 256 : 1024, LHIST_BIAS = LHIST / 2, NBAND = LEVEL == 1 ? 3 : 4 };
+    enum { LHIST = LEVEL == 1 ? 256 : 2048, LHIST_BIAS = LHIST / 2, NBAND = LEVEL == 1 ? 3 : 4 };
     uint32_t cnt[NP][LHIST];    // symbols [-LHIST/2, LHIST/2)
     uint32_t first[NP][LHIST];
     double rdiv[NBAND * KHG_RD_N];  // 1/divisor of band slot s at diagonal u: [s * KHG_RD_N + KHG_RD_PAD + u]
@@ -377,6 +381,7 @@ template <int LHIST>
 KHG_DEV int khg_count_rare(const KhgFwdArgs& a, const KhgFwdPlane& pl, uint32_t* lcnt, uint32_t* lfirst, KhgHot& hot, int q,
                            int stream, uint32_t raster)
 {
+    const int lh = LHIST == 256 ? 256 : a.lhist;  // bins in use, centred in the LHIST there is room for
     const uint32_t q1 = (uint32_t)(q + 1);
     if (q1 <= 2u) {
         hot += khg_hot_unit(q1);
@@ -399,7 +404,7 @@ KHG_DEV int khg_count_rare(const KhgFwdArgs& a, const KhgFwdPlane& pl, uint32_t*
         return q;
     }
     const int l = q + LHIST / 2;
-    if ((unsigned)l < (unsigned)LHIST) {
+    if ((unsigned)(q + lh / 2) < (unsigned)lh) {
         khg_lds_add(&lcnt[l], 1u);
         khg_lds_min(&lfirst[l], raster);
     } else {
@@ -534,8 +539,9 @@ KHG_DEV void khg_fwd_wg_body(const KhgFwdArgs& a, const KhgFwdPlane* pls, int wg
         uint32_t foa, fob;
         khg_fwd_row_offsets<SRC>(a, g, k0 - 2, foa, fob);
         khg_fwd_fetch<SRC>(a, g, raws[KHG_SLOT], foa, fob, lsrc[KHG_SLOT].col);
+        const int lh = LEVEL == 1 ? (int)SM::LHIST : a.lhist, l0 = SM::LHIST_BIAS - lh / 2;  // the bins in use
         for (int n = 0; n < NP; ++n)
-            for (int i = tid; i < SM::LHIST; i += 256) {
+            for (int i = l0 + tid; i < l0 + lh; i += 256) {
                 sh.cnt[n][i] = 0;
                 sh.first[n][i] = 0xFFFFFFFFu;
             }
@@ -649,8 +655,9 @@ KHG_DEV void khg_fwd_wg_body(const KhgFwdArgs& a, const KhgFwdPlane* pls, int wg
     KHG_BARRIER();
     KHG_FOR_THREADS(256)
     {
+        const int lh = LEVEL == 1 ? (int)SM::LHIST : a.lhist, l0 = SM::LHIST_BIAS - lh / 2;
         for (int n = 0; n < NP; ++n)
-            for (int i = tid; i < SM::LHIST; i += 256) {
+            for (int i = l0 + tid; i < l0 + lh; i += 256) {
                 uint32_t c = sh.cnt[n][i];
                 if (c) {
                     int bin = i - SM::LHIST_BIAS + KHG_SYM_BIAS;

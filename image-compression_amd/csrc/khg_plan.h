@@ -265,6 +265,7 @@ static inline KhgFwdArgs khg_fwd_args_rgb(const KhgWorkspace& ws, const uint8_t*
     // a row of a chroma workgroup (Cb and Cr together, half the strips' pixels each) costs 2.25 luma rows (measured)
     const int first[2] = {0, 1}, count[2] = {1, 2}, weight[2] = {4, 9};
     a.nplanes = luma_only ? 1 : 3;
+    a.lhist = 256;
     khg_fwd_plan_grid(&a, luma_only ? 1 : 2, first, count, weight);
     return a;
 }
@@ -281,6 +282,7 @@ static inline KhgFwdArgs khg_fwd_args_planes(const KhgWorkspace& ws, int rows, i
         khg_fwd_plane(&a.pl[p], ws, rows, cols, lvl, p, level, coef ? coef[p] : nullptr, tile, ycbcr ? ycbcr[p] : nullptr);
     const int first[3] = {0, 1, 2}, count[3] = {1, 1, 1}, weight[3] = {1, 1, 1};
     a.nplanes = 3;
+    a.lhist = level == 1 ? 256 : (lvl == 0 ? 2048 : 1024);  // Normal preset: luma LL symbols reach 1009 (255 * 4 / 1.011)
     khg_fwd_plan_grid(&a, 3, first, count, weight);
     return a;
 }
