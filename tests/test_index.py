@@ -141,6 +141,27 @@ def test_gpu_index(codec, shape):
 
 
 @pytest.mark.gpu
+def test_gpu_index_through_the_host_entry_points(codec):
+    """khg_encode / khg_encode_ycbcr / khg_encode_bgr_dev honour the context's format too; the row-tile steps do not."""
+    import torch
+    rgb = synth_frame(264, 520, 2, 1)
+    v1 = codec.encode(rgb, 1)
+    want = v1 + O.index_trailer(v1)
+    codec.set_format(2)
+    try:
+        assert codec.encode(rgb, 1) == want
+        y, cb, cr = O.rgb_to_ycbcr(rgb)
+        assert codec.encode_ycbcr(y, cb, cr, 1) == want
+        pixels, stride = S.bgr_pixels(rgb)
+        out = torch.zeros(codec.comp_bound(264, 520) + codec.index_bound(264, 520), dtype=torch.uint8, device="cuda")
+        codec.encode_bgr_dev(torch.from_numpy(pixels).cuda(), stride, 264, 520, 1, out)
+        assert out[:codec.encode_result()].cpu().numpy().tobytes() == want
+    finally:
+        codec.set_format(1)
+    assert codec.encode(rgb, 1) == v1
+
+
+@pytest.mark.gpu
 def test_gpu_index_full_frame_and_stress():
     """An 8K frame: same pixels with and without the index; the stress pictures through both decoders."""
     import torch
