@@ -135,9 +135,9 @@ KHG_DEV int khg_tree_build(int k, uint64_t* heap, uint32_t* nfreq, uint32_t* par
 #endif
     int next = k;
     while (n != 1) {  // Huffman.h:96-105
-        uint32_t r = (uint32_t)khg_heap_pop(heap, n);
-        uint32_t l = (uint32_t)khg_heap_pop(heap, n);
-        uint32_t sum = (uint32_t)(int)(nfreq[l] + nfreq[r]);
+        const uint64_t er = khg_heap_pop(heap, n), el = khg_heap_pop(heap, n);  // entries carry their node's count
+        const uint32_t r = (uint32_t)er, l = (uint32_t)el;
+        uint32_t sum = (uint32_t)(int)((uint32_t)(el >> 32) + (uint32_t)(er >> 32));
         nfreq[next] = sum;
         parent[l] = (uint32_t)next;
         parent[r] = (uint32_t)next | 0x80000000u;
