@@ -852,12 +852,18 @@ KHG_DEV void khg_dec_map_body(const KhgDecArgs& a, uint32_t blk, KhgDecSmem<MO>&
 
 struct KhgDecChainSmem {
     uint32_t map[KHG_DEC_BLOCK * KHG_MAXOFF];
+    uint32_t gmap[16 * KHG_MAXOFF];  // 16 workgroups in a row entered at offset o -> (landing offset << 24) | codewords
+    uint32_t goff[16], gout[16];     // state at the start of each such group
+    uint32_t off, out;               // state carried from one batch of 256 workgroups to the next
     uint32_t total;
 };
 
-// bid = colour component.  Thread 0 walks the workgroup maps from bit 0; the others stage the maps
-// in LDS and afterwards zero-fill raster cells past the decoded symbols (Huffman.h:35: the matrix
-// starts zero-initialised).
+// bid = colour component.  Follows the workgroup maps from bit 0 of the stream: where each workgroup is entered and
+// how many codewords precede it; afterwards zero-fills raster cells past the decoded symbols (Huffman.h:35: the matrix
+// starts zero-initialised).  The walk is a chain of dependent lookups, one per workgroup; composition is associative,
+// so 256 workgroups at a time (their maps staged in LDS) it goes in three short sweeps instead: 16 groups of 16
+// workgroups composed for every entry offset (one thread per group and offset), one thread chaining the 16 group
+// maps, 16 threads walking their group from its true entry.
 KHG_DEV void khg_dec_chain_body(const KhgDecArgs& a, int bid, KhgDecChainSmem& sh)
 {
     if (!a.hdr->ok) return;
@@ -865,36 +871,73 @@ KHG_DEV void khg_dec_chain_body(const KhgDecArgs& a, int bid, KhgDecChainSmem& s
     const uint32_t nbits = (uint32_t)a.hdr->nbits[p];
     const uint32_t nb = (nbits + KHG_BLK_BITS - 1) / KHG_BLK_BITS;  // active workgroups of this plane
     KhgBlkInfo* blk = a.blk + a.blk0[p];
-    uint32_t off_c[KHG_NSLOT(256)], out_c[KHG_NSLOT(256)];
+    const uint32_t M = (uint32_t)a.hdr->maxlen[p] <= (uint32_t)KHG_MAXOFF ? (uint32_t)a.hdr->maxlen[p] : 0u;  // offsets in use
     KHG_FOR_THREADS(256)
     {
-        off_c[KHG_SLOT] = 0;
-        out_c[KHG_SLOT] = 0;
+        if (tid == 0) {
+            sh.off = M ? 0 : KHG_OFF_NONE;
+            sh.out = 0;
+        }
     }
     for (uint32_t t0 = 0; t0 < nb; t0 += KHG_DEC_BLOCK) {
         const uint32_t nt = nb - t0 < KHG_DEC_BLOCK ? nb - t0 : KHG_DEC_BLOCK;
         KHG_FOR_THREADS(256)
         {
-            for (uint32_t i = (uint32_t)tid; i < nt * KHG_MAXOFF; i += 256)
-                sh.map[i] = blk[t0 + i / KHG_MAXOFF].map[i % KHG_MAXOFF];
+            for (uint32_t i = (uint32_t)tid; i < nt * M; i += 256) {  // the M entries in use of every map
+                const uint32_t b = i / M, o = i - b * M;
+                sh.map[b * KHG_MAXOFF + o] = blk[t0 + b].map[o];
+            }
+        }
+        KHG_BARRIER();
+        KHG_FOR_THREADS(256)
+        {
+            for (uint32_t idx = (uint32_t)tid; idx < 16 * M; idx += 256) {
+                const uint32_t g = idx / M, o = idx - g * M;
+                uint32_t off = o, tot = 0;
+                for (uint32_t b = 16 * g; b < 16 * g + 16 && b < nt; ++b) {
+                    if (off < M) {  // else: the stream has ended (KHG_OFF_NONE)
+                        const uint32_t e = sh.map[b * KHG_MAXOFF + off];
+                        tot += e & 0xFFFFFFu;  // at most 16 x 2^16 codewords
+                        off = e >> 24;
+                    }
+                }
+                sh.gmap[g * KHG_MAXOFF + o] = ((off < M ? off : (uint32_t)KHG_OFF_NONE) << 24) | tot;
+            }
         }
         KHG_BARRIER();
         KHG_FOR_THREADS(256)
         {
             if (tid == 0) {
-                uint32_t off = off_c[KHG_SLOT], out = out_c[KHG_SLOT];
-                for (uint32_t b = 0; b < nt; ++b) {
-                    blk[t0 + b].start_off = off;
-                    blk[t0 + b].out = out;
-                    if (off != KHG_OFF_NONE) {
-                        uint32_t e = sh.map[b * KHG_MAXOFF + off];
-                        uint32_t tot = e & 0xFFFFFFu;
+                uint32_t off = sh.off, out = sh.out;
+                for (uint32_t g = 0; g < 16; ++g) {
+                    sh.goff[g] = off;
+                    sh.gout[g] = out;
+                    if (off < M) {
+                        const uint32_t e = sh.gmap[g * KHG_MAXOFF + off];
+                        const uint32_t tot = e & 0xFFFFFFu;
                         out = out + tot < out ? 0xFFFFFFFFu : out + tot;
                         off = e >> 24;
                     }
                 }
-                off_c[KHG_SLOT] = off;
-                out_c[KHG_SLOT] = out;
+                sh.off = off;
+                sh.out = out;
+            }
+        }
+        KHG_BARRIER();
+        KHG_FOR_THREADS(256)
+        {
+            if (tid < 16) {
+                uint32_t off = sh.goff[tid], out = sh.gout[tid];
+                for (uint32_t b = 16 * (uint32_t)tid; b < 16 * (uint32_t)tid + 16 && b < nt; ++b) {
+                    blk[t0 + b].start_off = off;
+                    blk[t0 + b].out = out;
+                    if (off < M) {
+                        const uint32_t e = sh.map[b * KHG_MAXOFF + off];
+                        const uint32_t tot = e & 0xFFFFFFu;
+                        out = out + tot < out ? 0xFFFFFFFFu : out + tot;
+                        off = e >> 24 < M ? e >> 24 : (uint32_t)KHG_OFF_NONE;
+                    }
+                }
             }
         }
         KHG_BARRIER();
@@ -902,7 +945,7 @@ KHG_DEV void khg_dec_chain_body(const KhgDecArgs& a, int bid, KhgDecChainSmem& s
     KHG_FOR_THREADS(256)
     {
         if (tid == 0) {
-            uint32_t out = out_c[KHG_SLOT];
+            uint32_t out = sh.out;
             if (out > a.n[p]) {
                 khg_set_status(&a.res->status, -3);  // the reference would write out of bounds
                 out = a.n[p];
