@@ -149,12 +149,16 @@ KHG_DEV int32_t khg_load_le32(const uint8_t* p)
     return (int32_t)((uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24));
 }
 
-// One thread.  Reader.h:5-23 plus the consistency checks the reference omits.
+// One thread.  Reader.h:5-23 plus the consistency checks the reference omits.  Starts the job's result block afresh
+// (it is the first kernel of every decode).
 KHG_DEV void khg_dec_header_body(const KhgDecArgs& a)
 {
     KHG_FOR_THREADS(256)
     {
         if (tid == 0) {
+            KhgResult zero;
+            __builtin_memset(&zero, 0, sizeof zero);
+            *a.res = zero;
             KhgDecHeader* h = a.hdr;
             const uint8_t* c = a.comp;
             int ok = a.len >= 36;

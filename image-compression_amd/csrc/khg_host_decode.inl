@@ -68,7 +68,6 @@ static int khg_decode_enqueue(khg_ctx* c, const uint8_t* d_comp, size_t len, int
     KHG_HIP(hipSetDevice(c->device));
     if ((rc = khg_begin(c, st))) return rc;
     const KhgDecArgs d = khg_dec_args(c->ws, c->dws, d_comp, len, rows, cols);
-    KHG_HIP(hipMemsetAsync(c->ws.res, 0, sizeof(KhgResult), st));
     hipLaunchKernelGGL(khg_dec_header_kernel, dim3(1), dim3(256), 0, st, d);
     hipLaunchKernelGGL(khg_dec_tree_kernel, dim3(3), dim3(256), 0, st, d);
     // the three streams together are shorter than the file, and each ends inside one more workgroup at most

@@ -188,7 +188,6 @@ extern "C" int khg_tile_decode_map_dev(khg_ctx* c, const uint8_t* d_comp, size_t
         const uint32_t cap = (p < 2 ? d.blk0[p + 1] : d.nblocks) - d.blk0[p];
         if (c->tdec_nb[p] > cap) c->tdec_nb[p] = cap;  // the device-side header check fails such a file
     }
-    KHG_HIP(hipMemsetAsync(c->ws.res, 0, sizeof(KhgResult), st));
     for (int p = 0; p < 3; ++p)
         if (c->tdec_nb[p])
             KHG_HIP(hipMemsetAsync(c->dws.blk + d.blk0[p], 0, (size_t)c->tdec_nb[p] * sizeof(KhgBlkInfo), st));

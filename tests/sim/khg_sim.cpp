@@ -175,8 +175,7 @@ static int sim_decode(SimWs& S, const uint8_t* comp, size_t len, int rows, int c
     std::vector<uint8_t> buf((len + 3) & ~(size_t)3, 0);
     memcpy(buf.data(), comp, len);
     KhgDecArgs d = khg_dec_args(S.ws, S.dws, buf.data(), len, rows, cols);
-    memset(S.ws.res, 0, sizeof(KhgResult));
-    khg_dec_header_body(d);
+    khg_dec_header_body(d);  // clears the result block itself
     KhgDecTreeSmem* tsh = new KhgDecTreeSmem;
     for (int p = 0; p < 3; ++p) khg_dec_tree_body(d, p, *tsh);
     delete tsh;
@@ -478,7 +477,6 @@ int khgsim_tile_decode_map(void* h, const uint8_t* comp, size_t len, int rows, i
         if (T->nb[p] > cap) T->nb[p] = cap;
         memset(T->S.dws.blk + d.blk0[p], 0, (size_t)T->nb[p] * sizeof(KhgBlkInfo));
     }
-    memset(T->S.ws.res, 0, sizeof(KhgResult));
     khg_dec_header_body(d);
     KhgDecTreeSmem* tsh = new KhgDecTreeSmem;
     for (int p = 0; p < 3; ++p) khg_dec_tree_body(d, p, *tsh);
