@@ -9,6 +9,18 @@ struct KhgSsimArgs {
     double* blocks;        // [(height/8) * (width/8)] per-block SSIM in raster order
 };
 
+// Dot product of the four bytes of two words.
+#ifdef KHG_SIM
+KHG_DEV uint32_t khg_dot4(uint32_t x, uint32_t y)
+{
+    uint32_t s = 0;
+    for (int i = 0; i < 4; ++i) s += ((x >> (8 * i)) & 255u) * ((y >> (8 * i)) & 255u);
+    return s;
+}
+#else
+KHG_DEV uint32_t khg_dot4(uint32_t x, uint32_t y) { return __builtin_amdgcn_udot4(x, y, 0u, false); }
+#endif
+
 // One thread per block.  All sums are exact in f64 (integers, or multiples of 1/4096 below 2^28),
 // so only the final expression of SSIM.h:52-53 rounds, in the reference's order.
 KHG_DEV void khg_ssim_body(const KhgSsimArgs& a, uint32_t bid)
@@ -21,21 +33,31 @@ KHG_DEV void khg_ssim_body(const KhgSsimArgs& a, uint32_t bid)
             int by = (int)(blk / bw), bx = (int)(blk - (size_t)by * bw);
             const uint8_t* pa = a.a + (size_t)by * 8 * a.width + bx * 8;
             const uint8_t* pb = a.b + (size_t)by * 8 * a.width + bx * 8;
-            double s1 = 0.0, s2 = 0.0;
-            for (int i = 0; i < 8; ++i)
-                for (int j = 0; j < 8; ++j) {
-                    s1 += pa[(size_t)i * a.width + j];
-                    s2 += pb[(size_t)i * a.width + j];
+            // Every f64 value the reference forms up to here is exact: the sums of the 64 values (integers), the means
+            // (over 64), the differences from them (multiples of 1/64 below 256), their squares and products
+            // (multiples of 1/4096 below 2^16) and the running sums of those (below 2^22).  Exact values do not depend
+            // on how they were added up, so they are taken from integer dot products of the rows' bytes:
+            //   sum (p - m)^2 = (64 sum p^2 - (sum p)^2) / 64,   sum (p - m)(q - n) = (64 sum p q - sum p sum q) / 64.
+            uint32_t sa = 0, sb = 0, saa = 0, sbb = 0, sab = 0;
+            KHG_UNROLL
+            for (int i = 0; i < 8; ++i) {
+                uint32_t x[2], y[2];
+                __builtin_memcpy(x, pa + (size_t)i * a.width, 8);
+                __builtin_memcpy(y, pb + (size_t)i * a.width, 8);
+                KHG_UNROLL
+                for (int h = 0; h < 2; ++h) {
+                    sa += khg_dot4(x[h], 0x01010101u);
+                    sb += khg_dot4(y[h], 0x01010101u);
+                    saa += khg_dot4(x[h], x[h]);
+                    sbb += khg_dot4(y[h], y[h]);
+                    sab += khg_dot4(x[h], y[h]);
                 }
+            }
+            const double s1 = (double)sa, s2 = (double)sb;
             double avg1 = s1 / 64.0, avg2 = s2 / 64.0;  // SSIM.h:14-21
-            double v1 = 0.0, v2 = 0.0, cv = 0.0;
-            for (int i = 0; i < 8; ++i)
-                for (int j = 0; j < 8; ++j) {
-                    double da = pa[(size_t)i * a.width + j] - avg1, db = pb[(size_t)i * a.width + j] - avg2;
-                    v1 += da * da;  // SSIM.h:23-30
-                    v2 += db * db;
-                    cv += da * db;  // SSIM.h:32-40
-                }
+            const double v1 = (double)(64u * saa - sa * sa) / 64.0;  // SSIM.h:23-30
+            const double v2 = (double)(64u * sbb - sb * sb) / 64.0;
+            const double cv = (double)((long long)(64u * sab) - (long long)(sa * sb)) / 64.0;  // SSIM.h:32-40
             double var1 = v1 / 64.0, var2 = v2 / 64.0, cov = cv / 64.0;
             double L = 255.0;
             double K1 = 0.01, K2 = 0.03;
@@ -379,23 +401,7 @@ struct KhgSseSmem {
 // Integer sums of (I-O)^2 per channel: exactly what GetMse accumulates in a double (every
 // partial sum is an integer below 2^53).
 // Sum of (x - y)^2 over the four bytes of two words: sum x^2 + sum y^2 - 2 sum x y, three byte dot products.
-#ifdef KHG_SIM
-KHG_DEV uint32_t khg_sqdiff4(uint32_t x, uint32_t y)
-{
-    uint32_t s = 0;
-    for (int i = 0; i < 4; ++i) {
-        const int d = (int)((x >> (8 * i)) & 255u) - (int)((y >> (8 * i)) & 255u);
-        s += (uint32_t)(d * d);
-    }
-    return s;
-}
-#else
-KHG_DEV uint32_t khg_sqdiff4(uint32_t x, uint32_t y)
-{
-    const uint32_t xx = __builtin_amdgcn_udot4(x, x, 0u, false), yy = __builtin_amdgcn_udot4(y, y, 0u, false);
-    return xx + yy - 2u * __builtin_amdgcn_udot4(x, y, 0u, false);
-}
-#endif
+KHG_DEV uint32_t khg_sqdiff4(uint32_t x, uint32_t y) { return khg_dot4(x, x) + khg_dot4(y, y) - 2u * khg_dot4(x, y); }
 
 KHG_DEV void khg_sse_body(const KhgSseArgs& a, uint32_t bid, uint32_t nblk, KhgSseSmem& sh)
 {
