@@ -36,6 +36,11 @@
         }                                          \
         (total) = run_;                            \
     }
+// N such scans behind one barrier: excl[j][t], val[j][t], lds[j][4], total[j] for j < N.
+#define KHG_WG_EXCL_SCAN_N(N, excl, val, lds, total)                                           \
+    {                                                                                          \
+        for (int j_ = 0; j_ < (N); ++j_) KHG_WG_EXCL_SCAN((excl)[j_], (val)[j_], (lds)[j_], (total)[j_]) \
+    }
 // Workgroup collective (NW waves, not inside KHG_FOR_THREADS): the sums of two doubles over all threads, to every
 // thread, for values whose sum does not depend on the order (integers below 2^53).  lds: a KhgWgSum2 nobody else
 // touches until the next barrier but one.
@@ -82,14 +87,23 @@ static inline void khg_chain_store(uint64_t* p, uint64_t v) { *p = v; }
 #define KHG_UNROLL _Pragma("unroll")
 #define KHG_NOUNROLL _Pragma("nounroll")
 // Inclusive prefix sum over the lanes of a wave.
+// v + (v of the lanes the DPP control names); lanes without a source (shifted in from outside a row, or excluded by
+// the row mask) add zero.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t khg_dpp_add_u32(uint32_t v)
+{
+    return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+// Six DPP additions, no LDS traffic: shifts by 1, 2, 4, 8 inside the rows of 16 lanes, then each row's total into
+// the rows above it.
 __device__ __forceinline__ uint32_t khg_wave_incl_scan(uint32_t v)
 {
-    const int lane = (int)(threadIdx.x & 63u);
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t t = (uint32_t)__shfl_up((int)v, d, 64);
-        if (lane >= d) v += t;
-    }
+    v = khg_dpp_add_u32<0x111, 0xf>(v);  // row_shr:1
+    v = khg_dpp_add_u32<0x112, 0xf>(v);  // row_shr:2
+    v = khg_dpp_add_u32<0x114, 0xf>(v);  // row_shr:4
+    v = khg_dpp_add_u32<0x118, 0xf>(v);  // row_shr:8
+    v = khg_dpp_add_u32<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+    v = khg_dpp_add_u32<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3
     return v;
 }
 // Workgroup collective (256 threads, like KHG_BARRIER not inside KHG_FOR_THREADS): excl[0] = the sum of val of all
@@ -109,6 +123,30 @@ __device__ __forceinline__ uint32_t khg_wave_incl_scan(uint32_t v)
         }                                                             \
         (excl)[0] = base_ + inc_ - (val)[0];                          \
         (total) = tot_;                                               \
+    }
+// N such scans behind one barrier: excl[j][0], val[j][0], lds[j][4], total[j] for j < N.
+#define KHG_WG_EXCL_SCAN_N(N, excl, val, lds, total)                               \
+    {                                                                              \
+        uint32_t inc_[N];                                                          \
+        const uint32_t w_ = threadIdx.x >> 6;                                      \
+        _Pragma("unroll") for (int j_ = 0; j_ < (N); ++j_)                        \
+        {                                                                          \
+            inc_[j_] = khg_wave_incl_scan((val)[j_][0]);                           \
+            if ((threadIdx.x & 63u) == 63u) (lds)[j_][w_] = inc_[j_];              \
+        }                                                                          \
+        __syncthreads();                                                           \
+        _Pragma("unroll") for (int j_ = 0; j_ < (N); ++j_)                        \
+        {                                                                          \
+            uint32_t base_ = 0, tot_ = 0;                                          \
+            _Pragma("unroll") for (uint32_t i_ = 0; i_ < 4; ++i_)                 \
+            {                                                                      \
+                const uint32_t s_ = (lds)[j_][i_];                                 \
+                base_ += i_ < w_ ? s_ : 0u;                                        \
+                tot_ += s_;                                                        \
+            }                                                                      \
+            (excl)[j_][0] = base_ + inc_[j_] - (val)[j_][0];                       \
+            (total)[j_] = tot_;                                                    \
+        }                                                                          \
     }
 // v + (v of the lanes the DPP control names); lanes the row mask excludes add zero.
 template <int CTRL, int ROW_MASK>

@@ -330,6 +330,12 @@ extern "C" int khg_debug_fwd(uint32_t* host, size_t words)
     if (words > 4 * 8192) words = 4 * 8192;
     return hipMemcpyFromSymbol(host, HIP_SYMBOL(khg_dbg_fwd), words * 4) == hipSuccess ? 0 : KHG_ERR_HIP;
 }
+// Developer build only: the single-pass packer's per-entry clock stamps (eight words per entry).
+extern "C" int khg_debug_packer(khg_ctx* c, uint64_t* host, size_t words)
+{
+    KHG_HIP(hipMemcpy(host, c->ws.chunk_off, words * 8, hipMemcpyDeviceToHost));
+    return KHG_OK;
+}
 // Developer build only: the per-workgroup records of the last decode (timing stamps in pad_).
 extern "C" int khg_debug_blocks(khg_ctx* c, void* host, size_t bytes, uint32_t* blk0, uint32_t* nblocks)
 {

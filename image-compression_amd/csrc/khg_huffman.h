@@ -10,7 +10,7 @@
 #pragma once
 #include "khg_common.h"
 
-enum { KHG_CHAIN_HEAD = 2 };  // words of KhgEncArgs::chain before the per-chunk state ([0]: next ticket)
+enum { KHG_CHAIN_HEAD = 16 };  // words of KhgEncArgs::chain before the per-entry state ([0]: next ticket, alone in its 128-byte line)
 
 enum {
     KHG_TREE_LDS_K = 4096,  // tables up to this size build their tree in LDS
@@ -605,17 +605,22 @@ struct KhgPackSmem {
 };
 
 // Table entry of symbol v: (length << 56) | code.  hot: the workgroup's LDS copy of the entries of -128 .. 127.
-KHG_DEV uint64_t khg_pack_code_lds(const uint64_t* hot, const uint64_t* ctab, int v)
+template <int NHOT>
+KHG_DEV uint64_t khg_pack_code_lds_n(const uint64_t* hot, const uint64_t* ctab, int v)
 {
     // the LDS entry is fetched unconditionally (index wrapped) and replaced on the rare path: a select between
     // an LDS and a global address would turn both into one flat load
-    const uint32_t h = (uint32_t)(v + KHG_HOT_SYMS / 2);
-    uint64_t c = hot[h & (KHG_HOT_SYMS - 1)];
-    if (h >= (uint32_t)KHG_HOT_SYMS) {
+    const uint32_t h = (uint32_t)(v + NHOT / 2);
+    uint64_t c = hot[h & (NHOT - 1)];
+    if (h >= (uint32_t)NHOT) {
         KHG_OPAQUE(c);  // the LDS load stays a load of its own
         c = ctab[v + KHG_SYM_BIAS];
     }
     return c;
+}
+KHG_DEV uint64_t khg_pack_code_lds(const uint64_t* hot, const uint64_t* ctab, int v)
+{
+    return khg_pack_code_lds_n<KHG_HOT_SYMS>(hot, ctab, v);
 }
 
 // ORs the n <= 64 bits of `bits` (right-aligned) into the workgroup's word buffer at bit position pos (first
@@ -880,6 +885,21 @@ KHG_DEV uint64_t khg_chain_group_start(const KhgEncArgs& a, uint32_t g, int lane
 #endif
 }
 
+// The single-pass packer's LDS tables: the codes of the symbols -64 .. 63 one by one, and the joint code of every PAIR
+// of symbols in -8 .. 7 (nearly all symbols of a detail band): one lookup and one merge for two symbols.
+enum { KHG_PS_HOT = 128 };
+#define KHG_PAIR_NONE (1ull << 63)  // no joint entry: a symbol without a code, or more than 56 bits together
+
+// Entry idx of the pair table: the first symbol's low four bits in bits 0-3 of idx, the second symbol's in bits 4-7.
+KHG_DEV uint64_t khg_pair_entry(const uint64_t* ctab, uint32_t idx)
+{
+    const int s0 = (int)((idx & 15u) ^ 8u) - 8, s1 = (int)(((idx >> 4) & 15u) ^ 8u) - 8;
+    const uint64_t c0 = ctab[s0 + KHG_SYM_BIAS], c1 = ctab[s1 + KHG_SYM_BIAS];
+    const uint32_t l0 = (uint32_t)(c0 >> 56), l1 = (uint32_t)(c1 >> 56);
+    if (l0 == 0 || l1 == 0 || l0 + l1 > (uint32_t)KHG_MAX_CODE_BITS) return KHG_PAIR_NONE;
+    return ((uint64_t)(l0 + l1) << 56) | ((c0 & 0x00FFFFFFFFFFFFFFull) << l1) | (c1 & 0x00FFFFFFFFFFFFFFull);
+}
+
 // The entry's last (up to 32) bits, from its last (up to 64) symbols: every code has at least one bit, so 32
 // symbols always suffice.  Wave 0.
 KHG_DEV uint32_t khg_entry_tail32(const KhgEncArgs& a, int p, const uint64_t* hot, uint32_t sym0, uint32_t sym1, int lane)
@@ -890,7 +910,7 @@ KHG_DEV uint32_t khg_entry_tail32(const KhgEncArgs& a, int p, const uint64_t* ho
     uint32_t tail = 0, pos = 0;
     if (lane == 0)
         for (uint32_t i = 0; i < n && pos < 32; ++i) {  // from the last symbol backwards
-            const uint64_t c = khg_pack_code_lds(hot, ctab, a.sym[p][sym1 - 1 - i]);
+            const uint64_t c = khg_pack_code_lds_n<KHG_PS_HOT>(hot, ctab, a.sym[p][sym1 - 1 - i]);
             const uint32_t len = (uint32_t)(c >> 56);
             tail |= (uint32_t)((c & 0x00FFFFFFFFFFFFFFull) << pos);
             pos += len;
@@ -901,7 +921,7 @@ KHG_DEV uint32_t khg_entry_tail32(const KhgEncArgs& a, int p, const uint64_t* ho
     uint32_t len = 0;
     uint64_t code = 0;
     if ((uint32_t)lane < n) {
-        const uint64_t c = khg_pack_code_lds(hot, ctab, a.sym[p][sym1 - 1 - (uint32_t)lane]);
+        const uint64_t c = khg_pack_code_lds_n<KHG_PS_HOT>(hot, ctab, a.sym[p][sym1 - 1 - (uint32_t)lane]);
         len = (uint32_t)(c >> 56);
         code = c & 0x00FFFFFFFFFFFFFFull;
     }
@@ -916,11 +936,62 @@ KHG_DEV uint32_t khg_entry_tail32(const KhgEncArgs& a, int p, const uint64_t* ho
 struct KhgPackScanSmem {
     uint32_t words[KHG_PACK_WORDS];
     uint32_t wave[KHG_SUPER][4];
-    uint64_t hot[KHG_HOT_SYMS];
+    uint64_t pair[256];        // khg_pair_entry
+    uint64_t hot[KHG_PS_HOT];  // (length << 56) | code of the symbols -64 .. 63
     uint64_t start;      // absolute bit position of the entry
     uint32_t carry[2];   // the 32 stream bits before the chunk being written (ping-pong between chunks)
     uint32_t nbits;      // a pad entry: its pad bits
 };
+
+// Bits a batch of chunks may have (the simulator's build lowers it, so that ordinary pictures take several batches).
+#ifndef KHG_PS_BATCH_BITS
+#define KHG_PS_BATCH_BITS ((KHG_PACK_WORDS - 3) * 32)
+#endif
+
+// The batch that begins with chunk j0 (whose first bit is bit base0 of the entry) ends before chunk j1 (returned):
+// as many whole chunks as fit KHG_PS_BATCH_BITS, at least one.  *bits: the batch's bits.
+KHG_DEV int khg_ps_batch_end(const uint32_t (&sub_base)[KHG_SUPER], const uint32_t (&tot)[KHG_SUPER], int nsub, int j0,
+                             uint32_t base0, uint32_t* bits)
+{
+    int j1 = nsub;
+    KHG_UNROLL
+    for (int j = KHG_SUPER - 1; j >= 1; --j)
+        if (j > j0 && j < nsub && sub_base[j] + tot[j] - base0 > (uint32_t)KHG_PS_BATCH_BITS) j1 = j;
+    uint32_t end = base0;
+    KHG_UNROLL
+    for (int j = 0; j < KHG_SUPER; ++j)
+        if (j == j1 - 1) end = sub_base[j] + tot[j];
+    *bits = end - base0;
+    return j1;
+}
+
+// Thread tid ORs its code strings of the chunks [j0, j1) into the word buffer; bit base0 of the entry is bit 0 of the
+// buffer.
+KHG_DEV void khg_ps_put_chunks(const KhgEncArgs& a, const KhgChainEntry& en, int p, KhgPackScanSmem& sh, int tid, int slot,
+                               const uint64_t (&acc)[KHG_SUPER][KHG_NSLOT(256)], const uint32_t (&tbs)[KHG_SUPER][KHG_NSLOT(256)],
+                               const uint32_t (&excl)[KHG_SUPER][KHG_NSLOT(256)], const uint32_t (&sub_base)[KHG_SUPER], int j0,
+                               int j1, uint32_t base0)
+{
+    const uint64_t* ctab = a.codetab + (size_t)p * KHG_NBINS;
+    KHG_UNROLL
+    for (int j = 0; j < KHG_SUPER; ++j) {
+        if (j < j0 || j >= j1) continue;
+        uint32_t pos = sub_base[j] - base0 + excl[j][slot];
+        const uint32_t tb = tbs[j][slot];
+        if (tb <= 64) {
+            khg_pack_put(sh.words, pos, acc[j][slot], tb);
+        } else {  // long codes: one at a time, from the symbols again (rare: kept small, not unrolled)
+            const uint32_t s0 = en.sym0 + (uint32_t)j * KHG_CHUNK + (uint32_t)tid * 8;
+            KHG_NOUNROLL
+            for (uint32_t i = s0; i < s0 + 8 && i < en.sym1; ++i) {
+                const uint64_t c = ctab[a.sym[p][i] + KHG_SYM_BIAS];
+                const uint32_t len = (uint32_t)(c >> 56);
+                khg_pack_put(sh.words, pos, c & 0x00FFFFFFFFFFFFFFull, len);
+                pos += len;
+            }
+        }
+    }
+}
 
 // One entry of the chain per workgroup (`t` = its ticket; the GPU kernel draws it, the simulator passes 0, 1, 2 ...).
 KHG_DEV void khg_packscan_body(const KhgEncArgs& a, uint32_t t, KhgPackScanSmem& sh)
@@ -931,9 +1002,17 @@ KHG_DEV void khg_packscan_body(const KhgEncArgs& a, uint32_t t, KhgPackScanSmem&
     const uint32_t group = t / KHG_CHAIN_GROUP, in_group = t % KHG_CHAIN_GROUP;
     const bool closes_group = in_group == KHG_CHAIN_GROUP - 1 || t == a.chain_entries - 1;
 
+#ifdef KHG_TIMING
+    KHG_FOR_THREADS(256) { if (tid == 0) a.chunk_off[8 * (size_t)t + 0] = khg_clock(); }
+#endif
     uint64_t acc[KHG_SUPER][KHG_NSLOT(256)];
     uint32_t tbs[KHG_SUPER][KHG_NSLOT(256)], excl[KHG_SUPER][KHG_NSLOT(256)];
-    KHG_FOR_THREADS(256) { sh.hot[tid] = ctab[KHG_SYM_BIAS - KHG_HOT_SYMS / 2 + tid]; }
+    KHG_FOR_THREADS(256)
+    {
+        if (tid < KHG_PS_HOT) sh.hot[tid] = ctab[KHG_SYM_BIAS - KHG_PS_HOT / 2 + tid];
+        sh.pair[tid] = khg_pair_entry(ctab, (uint32_t)tid);
+        for (uint32_t i = (uint32_t)tid; i < (uint32_t)KHG_PACK_WORDS; i += 256) sh.words[i] = 0;  // for the whole-entry path
+    }
     KHG_BARRIER();
     // every thread's eight symbols of every chunk as one code string (nearly always 64 bits or fewer)
     KHG_FOR_THREADS(256)
@@ -945,13 +1024,31 @@ KHG_DEV void khg_packscan_body(const KhgEncArgs& a, uint32_t t, KhgPackScanSmem&
             const int nv = (en.pad || s0 >= en.sym1) ? 0 : khg_load8(a.sym[p], s0, en.sym1, v);
             uint32_t tb = 0;
             uint64_t ac = 0;
+            // two symbols per lookup; `odd` collects what the pair table does not cover: a symbol outside -8 .. 7
+            // (bits 3 .. 15 of a symbol are not all alike), a pair without a joint entry, a ragged end
+            uint32_t w[4] = {0, 0, 0, 0};
+            if (nv == 8) __builtin_memcpy(w, v, 16);
+            uint32_t odd = nv == 8 ? 0u : 0x10u;
             KHG_UNROLL
-            for (int i = 0; i < 8; ++i) {
-                if (i < nv) {
-                    const uint64_t c = khg_pack_code_lds(sh.hot, ctab, v[i]);
-                    const uint32_t len = (uint32_t)(c >> 56);
-                    ac = (ac << len) | (c & 0x00FFFFFFFFFFFFFFull);  // meaningful while tb <= 64 (len <= 56)
-                    tb += len;
+            for (int q = 0; q < 4; ++q) {
+                odd |= (w[q] ^ (w[q] << 1)) & 0xFFF0FFF0u;
+                const uint64_t c = sh.pair[(w[q] & 15u) | ((w[q] >> 12) & 0xF0u)];
+                odd |= (uint32_t)(c >> 32) & 0x80000000u;
+                const uint32_t len = (uint32_t)(c >> 56) & 0x7Fu;
+                ac = (ac << len) | (c & 0x00FFFFFFFFFFFFFFull);  // meaningful while tb <= 64 (len <= 56)
+                tb += len;
+            }
+            if (odd) {  // one symbol at a time
+                tb = 0;
+                ac = 0;
+                KHG_UNROLL
+                for (int i = 0; i < 8; ++i) {
+                    if (i < nv) {
+                        const uint64_t c = khg_pack_code_lds_n<KHG_PS_HOT>(sh.hot, ctab, v[i]);
+                        const uint32_t len = (uint32_t)(c >> 56);
+                        ac = (ac << len) | (c & 0x00FFFFFFFFFFFFFFull);
+                        tb += len;
+                    }
                 }
             }
             acc[j][KHG_SLOT] = ac;
@@ -959,91 +1056,92 @@ KHG_DEV void khg_packscan_body(const KhgEncArgs& a, uint32_t t, KhgPackScanSmem&
         }
     }
     uint32_t tot[KHG_SUPER], sub_base[KHG_SUPER], total = 0;  // bits of each chunk, their offsets in the entry
+    KHG_WG_EXCL_SCAN_N(KHG_SUPER, excl, tbs, sh.wave, tot)
     for (int j = 0; j < KHG_SUPER; ++j) {
-        KHG_WG_EXCL_SCAN(excl[j], tbs[j], sh.wave[j], tot[j])
         sub_base[j] = total;
         total += tot[j];
     }
-    // publish the entry's bit count and tail, find its place, publish its end
-    KHG_FOR_THREADS(256)
-    {
-        if (tid < 64) {
-            bool ok = true;
-            if (!en.pad) {
-                const uint32_t tail = khg_entry_tail32(a, p, sh.hot, en.sym0, en.sym1, tid);
-                if (tid == 0) khg_chain_store(khg_chain_agg(a, t), KHG_CHAIN_VALID | ((uint64_t)total << 32) | tail);
-                if (closes_group) {  // the group's bit count, for look-backs that find no published group end nearby
+    // The entry is assembled in LDS, at bit 0 of words[0], in batches of whole chunks whose bits fit the word buffer:
+    // nearly always one batch of all eight (streams below seven bits per symbol), put together while wave 0 finds
+    // out where the entry goes -- three barriers per entry.  Further batches cost three barriers each.
+#ifdef KHG_TIMING
+    KHG_FOR_THREADS(256) { if (tid == 0) a.chunk_off[8 * (size_t)t + 1] = khg_clock(); }
+#endif
+    const int nsub = en.pad ? 1 : KHG_SUPER;
+    int j0 = 0;
+    uint32_t base0 = 0, batch_bits;
+    int j1 = khg_ps_batch_end(sub_base, tot, nsub, j0, base0, &batch_bits);
+    const bool last = en.pad && p == 2;  // the file's streams end here: the unfinished word is flushed too
+    bool first = true;
+    KHG_NOUNROLL
+    for (int cy = 0;; cy ^= 1) {
+        if (!first) {  // a further batch: the buffer is free once the batch before is written
+            KHG_BARRIER();
+            j0 = j1;
+            base0 += batch_bits;
+            j1 = khg_ps_batch_end(sub_base, tot, nsub, j0, base0, &batch_bits);
+            KHG_FOR_THREADS(256)
+            {
+                // the words the batch's bits reach, and one more (the funnel shift below reads a word past the last bit)
+                for (uint32_t i = (uint32_t)tid; i < ((batch_bits + 31) >> 5) + 2; i += 256) sh.words[i] = 0;
+            }
+            KHG_BARRIER();
+        }
+        KHG_FOR_THREADS(256)
+        {
+            // first batch: publish the entry's bit count and tail, find its place, publish its end
+            if (first && tid < 64) {
+                bool ok = true;
+                if (!en.pad) {
+                    const uint32_t tail = khg_entry_tail32(a, p, sh.hot, en.sym0, en.sym1, tid);
+                    if (tid == 0) khg_chain_store(khg_chain_agg(a, t), KHG_CHAIN_VALID | ((uint64_t)total << 32) | tail);
+                    if (closes_group) {  // the group's bit count, for look-backs that find no published group end nearby
+                        const uint64_t gsum = khg_chain_sum_window(khg_chain_agg(a, group * KHG_CHAIN_GROUP), in_group + 1, tid, &ok);
+                        if (tid == 0) khg_chain_store(khg_chain_gagg(a, group), KHG_CHAIN_VALID | gsum);
+                    }
+                }
+                // entries before this one in its group, then everything before the group
+                uint64_t start = khg_chain_sum_window(khg_chain_agg(a, group * KHG_CHAIN_GROUP), in_group, tid, &ok);
+                start += group ? khg_chain_group_start(a, group, tid, &ok) : 36 * 8;
+                uint32_t bits = total;
+                if (en.pad) bits = (uint32_t)((8 - (start & 7)) & 7);  // Compress.h:310-328: '0' bits up to a byte
+                if (tid == 0) {
+                    if (!ok) khg_set_status(&a.res->status, -6);
+                    if (en.pad) {  // the plane's lengths for the header
+                        uint64_t plane_start = 36 * 8;
+                        if (p > 0) plane_start = khg_chain_wait(khg_chain_pre(a, t - 1 - en.plane_entries)) & ~KHG_CHAIN_VALID;
+                        const uint64_t padded = start + bits - plane_start;
+                        a.res->bits[p] = padded >= ((uint64_t)1 << 31) ? -1 : (int32_t)padded;  // checked by khg_meta_body
+                        a.res->pads[p] = (int32_t)bits;
+                        khg_chain_store(khg_chain_agg(a, t), KHG_CHAIN_VALID | ((uint64_t)bits << 32));
+                    }
+                    khg_chain_store(khg_chain_pre(a, t), KHG_CHAIN_VALID | (start + bits));
+                    if (closes_group) khg_chain_store(khg_chain_gpre(a, group), KHG_CHAIN_VALID | (start + bits));
+                    sh.start = start;
+                    sh.carry[0] = (start & 31) ? khg_chain_tail_before(a, t) : 0;
+                    sh.nbits = bits;
+                }
+                if (closes_group && en.pad) {  // a pad entry's own count is only known now
                     const uint64_t gsum = khg_chain_sum_window(khg_chain_agg(a, group * KHG_CHAIN_GROUP), in_group + 1, tid, &ok);
                     if (tid == 0) khg_chain_store(khg_chain_gagg(a, group), KHG_CHAIN_VALID | gsum);
                 }
             }
-            // entries before this one in its group, then everything before the group
-            uint64_t start = khg_chain_sum_window(khg_chain_agg(a, group * KHG_CHAIN_GROUP), in_group, tid, &ok);
-            start += group ? khg_chain_group_start(a, group, tid, &ok) : 36 * 8;
-            uint32_t bits = total;
-            if (en.pad) bits = (uint32_t)((8 - (start & 7)) & 7);  // Compress.h:310-328: '0' bits up to a byte
-            if (tid == 0) {
-                if (!ok) khg_set_status(&a.res->status, -6);
-                if (en.pad) {  // the plane's lengths for the header
-                    uint64_t plane_start = 36 * 8;
-                    if (p > 0) plane_start = khg_chain_wait(khg_chain_pre(a, t - 1 - en.plane_entries)) & ~KHG_CHAIN_VALID;
-                    const uint64_t padded = start + bits - plane_start;
-                    a.res->bits[p] = padded >= ((uint64_t)1 << 31) ? -1 : (int32_t)padded;  // checked by khg_meta_body
-                    a.res->pads[p] = (int32_t)bits;
-                    khg_chain_store(khg_chain_agg(a, t), KHG_CHAIN_VALID | ((uint64_t)bits << 32));
-                }
-                khg_chain_store(khg_chain_pre(a, t), KHG_CHAIN_VALID | (start + bits));
-                if (closes_group) khg_chain_store(khg_chain_gpre(a, group), KHG_CHAIN_VALID | (start + bits));
-                sh.start = start;
-                sh.carry[0] = (start & 31) ? khg_chain_tail_before(a, t) : 0;
-                sh.nbits = bits;
-            }
-            if (closes_group && en.pad) {  // a pad entry's own count is only known now
-                const uint64_t gsum = khg_chain_sum_window(khg_chain_agg(a, group * KHG_CHAIN_GROUP), in_group + 1, tid, &ok);
-                if (tid == 0) khg_chain_store(khg_chain_gagg(a, group), KHG_CHAIN_VALID | gsum);
-            }
+#ifdef KHG_TIMING
+            if (first && tid == 0) a.chunk_off[8 * (size_t)t + 2] = khg_clock();
+#endif
+            khg_ps_put_chunks(a, en, p, sh, tid, KHG_SLOT, acc, tbs, excl, sub_base, j0, j1, base0);
         }
-    }
-    KHG_BARRIER();
-    if (en.pad) tot[0] = sh.nbits;
-    const bool last = en.pad && p == 2;  // the file's streams end here: the unfinished word is flushed too
-    const int nsub = en.pad ? 1 : KHG_SUPER;
-    for (int j = 0; j < nsub; ++j) {
-        const uint32_t bits = tot[j];
-        const uint64_t start = sh.start + sub_base[j];
+        KHG_BARRIER();
+#ifdef KHG_TIMING
+        KHG_FOR_THREADS(256) { if (first && tid == 0) a.chunk_off[8 * (size_t)t + 3] = khg_clock(); }
+#endif
+        first = false;
+        const uint32_t bits = en.pad ? sh.nbits : batch_bits;
+        const uint64_t start = sh.start + base0;
         const uint32_t r = (uint32_t)(start & 31);
         KHG_FOR_THREADS(256)
         {
-            // the words the chunk's bits reach, and one more (the funnel shift below reads a word past the last bit)
-            for (uint32_t i = (uint32_t)tid; i < ((bits + 31) >> 5) + 2; i += 256) sh.words[i] = 0;
-        }
-        KHG_BARRIER();
-        KHG_FOR_THREADS(256)
-        {
-            if (!en.pad) {
-                uint32_t pos = excl[j][KHG_SLOT];  // the chunk's first bit is the top bit of words[0]
-                const uint32_t tb = tbs[j][KHG_SLOT];
-                if (tb <= 64) {
-                    khg_pack_put(sh.words, pos, acc[j][KHG_SLOT], tb);
-                } else {  // long codes: one at a time, from the symbols again
-                    int16_t v[8];
-                    const int nv = khg_load8(a.sym[p], en.sym0 + (uint32_t)j * KHG_CHUNK + (uint32_t)tid * 8, en.sym1, v);
-                    KHG_UNROLL
-                    for (int i = 0; i < 8; ++i) {
-                        if (i < nv) {
-                            const uint64_t c = khg_pack_code_lds(sh.hot, ctab, v[i]);
-                            const uint32_t len = (uint32_t)(c >> 56);
-                            khg_pack_put(sh.words, pos, c & 0x00FFFFFFFFFFFFFFull, len);
-                            pos += len;
-                        }
-                    }
-                }
-            }
-        }
-        KHG_BARRIER();
-        KHG_FOR_THREADS(256)
-        {
-            const uint32_t carry = sh.carry[j & 1];
+            const uint32_t carry = sh.carry[cy];
             const uint32_t ncomplete = (r + bits) >> 5, rem = (r + bits) & 31;
             const uint32_t nwrite = ncomplete + ((last && rem) ? 1 : 0);
             const uint64_t w0 = start >> 5;
@@ -1060,11 +1158,14 @@ KHG_DEV void khg_packscan_body(const KhgEncArgs& a, uint32_t t, KhgPackScanSmem&
                     v = hi | (sh.words[k] >> r);
                 }
                 if (k < nwrite && fits) out32[k] = khg_bswap32(v);  // first stream bit = MSB of the first byte
-                if (k == ncomplete) sh.carry[(j + 1) & 1] = rem ? v >> (32 - rem) : 0;  // left to the next chunk
+                if (k == ncomplete) sh.carry[cy ^ 1] = rem ? v >> (32 - rem) : 0;  // left to the next batch
             }
         }
-        KHG_BARRIER();
+        if (j1 >= nsub) break;
     }
+#ifdef KHG_TIMING
+    KHG_FOR_THREADS(256) { if (tid == 0) a.chunk_off[8 * (size_t)t + 4] = khg_clock(); }
+#endif
 }
 
 // Header (Writer.h:9-23) and tables (Writer.h:34-41) behind the streams the single-pass packer wrote.  One

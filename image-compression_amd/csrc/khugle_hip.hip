@@ -62,11 +62,18 @@ static void khg_launch_job_init(const KhgWorkspace& ws, int rows, int cols, hipS
 }
 
 // khg_packscan_body: a workgroup draws its entry when it starts.
-__global__ __launch_bounds__(256) void khg_packscan_kernel(KhgEncArgs a)
+#ifndef KHG_PS_WAVES
+#define KHG_PS_WAVES 4  // waves per SIMD the register allocation aims at
+#endif
+__global__ __launch_bounds__(256, KHG_PS_WAVES) void khg_packscan_kernel(KhgEncArgs a)
 {
     __shared__ KhgPackScanSmem sh;
     __shared__ uint32_t ticket;
+#ifdef KHG_PS_NOTICKET  // measurement only: not safe
+    if (threadIdx.x == 0) ticket = blockIdx.x;
+#else
     if (threadIdx.x == 0) ticket = (uint32_t)atomicAdd((unsigned long long*)a.chain, 1ull);
+#endif
     __syncthreads();
     khg_packscan_body(a, ticket, sh);
 }

@@ -18,8 +18,10 @@ _lib = None
 def build(force=False):
     deps = [SRC] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     if force or not os.path.exists(SO) or os.path.getmtime(SO) < max(os.path.getmtime(d) for d in deps):
+        # KHG_PS_BATCH_BITS: the single-pass packer's LDS batches hold 20000 bits here instead of 114688, so that the
+        # entries of ordinary pictures are assembled in one batch (detail rows) and in several (rows with LL symbols)
         subprocess.check_call(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-I" + CSRC,
-                               "-o", SO, SRC])
+                               "-DKHG_PS_BATCH_BITS=20000", "-o", SO, SRC])
 
 
 def lib():

@@ -124,3 +124,22 @@ def test_encode_dev_async_and_errors(codec):
         codec.encode(np.zeros((3, 12, 16), np.uint8), 0)
     with pytest.raises(KhgError):
         codec.encode(np.zeros((3, 16, 16), np.uint8), 3)
+
+
+@pytest.mark.parametrize("kind", ["binary", "uniform"])
+def test_packer_batches_on_noise(codec, kind):
+    """Noise at the Normal preset: nearly every symbol lies outside the single-pass packer's pair table; black and
+    white noise has more than seven bits per luma symbol, so its entries of 16384 symbols do not fit the
+    workgroup's word buffer and are assembled in several batches."""
+    import oracle_py as O
+    rng = np.random.default_rng(5)
+    if kind == "binary":
+        rgb = (rng.integers(0, 2, (3, 512, 512), dtype=np.uint8) * 255).astype(np.uint8)
+    else:
+        rgb = rng.integers(0, 256, (3, 512, 512), dtype=np.uint8)
+    want = O.encode(rgb, 0)
+    if kind == "binary":
+        assert O.peek(want).y_len > 7 * 512 * 512
+    comp = codec.encode(rgb, 0)
+    assert comp == want
+    assert np.array_equal(codec.decode(comp), O.decode(want))

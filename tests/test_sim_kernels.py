@@ -62,6 +62,16 @@ def test_single_pass_packer_over_several_groups_of_entries():
     assert rc == 0 and comp == O.encode(rgb, 1)
 
 
+@pytest.mark.parametrize("lvl", [0, 1])
+def test_single_pass_packer_on_noise(lvl):
+    """White noise: nearly every symbol lies outside the packer's pair table (-8 .. 7), and an entry of 16384 symbols
+    (four to six bits each) is assembled in several batches (the simulator's build holds 20000 bits per batch)."""
+    rng = np.random.default_rng(77 + lvl)
+    rgb = rng.integers(0, 256, (3, 256, 384), dtype=np.uint8)
+    rc, comp = S.encode(rgb, lvl)
+    assert rc == 0 and comp == O.encode(rgb, lvl)
+
+
 @pytest.mark.parametrize("name,lvl", [("cat", 1), ("couple", 0), ("library", 2), ("lena", 1), ("baboon", 0)])
 def test_run_images(run_images, name, lvl):
     rgb = run_images[name]

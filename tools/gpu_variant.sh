@@ -13,7 +13,7 @@ for L in "$@"; do
 import csv, glob
 f = glob.glob("$R/gpurun_out/var_${TAG}_$N/**/*kernel_stats.csv", recursive=True)[0]
 for r in list(csv.DictReader(open(f))):
-    if "fwd" in r["Name"] or "inv" in r["Name"]:
+    if any(k in r["Name"] for k in "${KHG_VAR_FILTER:-fwd,inv}".split(",")):
         print("   %-50s calls %4s avg %8.1f us" % (r["Name"][:50], r["Calls"], float(r["AverageNs"]) / 1e3))
 PY
 done
