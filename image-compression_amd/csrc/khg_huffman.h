@@ -1038,17 +1038,26 @@ KHG_DEV void khg_packscan_body(const KhgEncArgs& a, uint32_t t, KhgPackScanSmem&
                 ac = (ac << len) | (c & 0x00FFFFFFFFFFFFFFull);  // meaningful while tb <= 64 (len <= 56)
                 tb += len;
             }
-            if (odd) {  // one symbol at a time
+            if (odd) {  // one symbol at a time: all eight from the LDS table, or all eight from the global one
+                uint64_t c[8];
+                uint32_t far = 0;
+                KHG_UNROLL
+                for (int i = 0; i < 8; ++i) {
+                    const uint32_t h = (uint32_t)(v[i] + KHG_PS_HOT / 2);
+                    far |= h;
+                    c[i] = sh.hot[h & (KHG_PS_HOT - 1)];
+                }
+                if (far >= (uint32_t)KHG_PS_HOT) {
+                    KHG_UNROLL
+                    for (int i = 0; i < 8; ++i) c[i] = ctab[(i < nv ? v[i] : 0) + KHG_SYM_BIAS];
+                }
                 tb = 0;
                 ac = 0;
                 KHG_UNROLL
                 for (int i = 0; i < 8; ++i) {
-                    if (i < nv) {
-                        const uint64_t c = khg_pack_code_lds_n<KHG_PS_HOT>(sh.hot, ctab, v[i]);
-                        const uint32_t len = (uint32_t)(c >> 56);
-                        ac = (ac << len) | (c & 0x00FFFFFFFFFFFFFFull);
-                        tb += len;
-                    }
+                    const uint32_t len = i < nv ? (uint32_t)(c[i] >> 56) : 0u;
+                    ac = (ac << len) | (i < nv ? c[i] & 0x00FFFFFFFFFFFFFFull : 0ull);
+                    tb += len;
                 }
             }
             acc[j][KHG_SLOT] = ac;
