@@ -71,6 +71,7 @@ KHG_DEV uint64_t khg_heap_pop(uint64_t* heap, int& n)
         uint64_t value = heap[len];
         heap[len] = top;
         int hole = 0, child = 0;
+        uint64_t up = 0;  // the entry moved last, i.e. what the hole's parent holds now
         // heap[] starts 8 bytes past a 16-byte boundary, so the sibling pair (2i+1, 2i+2) is one aligned 16-byte load
         const int lim = (len - 1) / 2;
         // two levels per memory round trip while both are complete: the children of `child` and the
@@ -91,6 +92,7 @@ KHG_DEV uint64_t khg_heap_pop(uint64_t* heap, int& n)
             }
             heap[hole] = pick;
             heap[la ? c2 - 1 : c2] = pick2;
+            up = pick2;
             hole = c4;
             child = c4;
         }
@@ -103,14 +105,19 @@ KHG_DEV uint64_t khg_heap_pop(uint64_t* heap, int& n)
                 pick = pr.a;
             }
             heap[hole] = pick;
+            up = pick;
             hole = child;
         }
         if ((len & 1) == 0 && child == (len - 2) / 2) {
             child = 2 * (child + 1);
-            heap[hole] = heap[child - 1];
+            up = heap[child - 1];
+            heap[hole] = up;
             hole = child - 1;
         }
-        khg_heap_sift_up(heap, hole, 0, value);
+        // __push_heap from the hole: its first comparison is with the entry just moved, still in a register; the
+        // re-inserted entry nearly always stays where the hole is
+        if (hole > 0 && khg_heap_comp(up, value)) khg_heap_sift_up(heap, hole, 0, value);
+        else heap[hole] = value;
     }
     n--;
     return top;
@@ -126,9 +133,11 @@ KHG_DEV int khg_tree_build(int k, uint64_t* heap, uint32_t* nfreq, uint32_t* par
 #ifdef KHG_TIMING
     long long t0 = wall_clock64();
 #endif
-    for (int i = 0; i < k; ++i) {  // Huffman.h:91-94
-        heap[n++] = 0;
-        khg_heap_sift_up(heap, n - 1, 0, ((uint64_t)nfreq[i] << 32) | (uint32_t)i);
+    uint32_t fnext = nfreq[0];
+    for (int i = 0; i < k; ++i) {  // Huffman.h:91-94; the next count is fetched while this one sifts up
+        const uint32_t f = fnext;
+        fnext = nfreq[i + 1 < k ? i + 1 : i];
+        khg_heap_sift_up(heap, n++, 0, ((uint64_t)f << 32) | (uint32_t)i);
     }
 #ifdef KHG_TIMING
     long long t1 = wall_clock64();
@@ -143,8 +152,7 @@ KHG_DEV int khg_tree_build(int k, uint64_t* heap, uint32_t* nfreq, uint32_t* par
         parent[r] = (uint32_t)next | 0x80000000u;
         left[next] = (int32_t)l;
         right[next] = (int32_t)r;
-        heap[n++] = 0;
-        khg_heap_sift_up(heap, n - 1, 0, ((uint64_t)sum << 32) | (uint32_t)next);
+        khg_heap_sift_up(heap, n++, 0, ((uint64_t)sum << 32) | (uint32_t)next);
         next++;
     }
 #ifdef KHG_TIMING
