@@ -122,6 +122,37 @@ static int sim_encode(SimWs& S, const uint8_t* r, const uint8_t* g, const uint8_
     return S.ws.res->status;
 }
 
+// The entropy coder alone, on symbol planes given by the caller (tests craft code tables no picture would give):
+// histogram and first raster indices as the forward kernels leave them, then the table, packer and header kernels.
+int khgsim_pack_symbols(const int16_t* qy, const int16_t* qcb, const int16_t* qcr, int rows, int cols, int lvl,
+                        uint8_t* out, size_t cap, size_t* out_len) {
+    if (!khg_dims_ok(rows, cols) || lvl < 0 || lvl > 2) return -1;
+    SimWs S(rows, cols);
+    KhgWorkspace& ws = S.ws;
+    memset(ws.hist_cnt, 0, 3 * KHG_NBINS * 4);
+    memset(ws.hist_first, 0xFF, 3 * KHG_NBINS * 4);
+    memset(ws.res, 0, sizeof(KhgResult));
+    const int16_t* q[3] = {qy, qcb, qcr};
+    for (int p = 0; p < 3; ++p) {
+        const size_t n = (size_t)rows * cols / (p ? 4 : 1);
+        memcpy(ws.sym[p], q[p], n * 2);
+        for (size_t i = 0; i < n; ++i) {
+            const int v = q[p][i];
+            if (v < -KHG_SYM_BIAS || v >= KHG_SYM_BIAS) return -1;
+            const size_t bin = (size_t)p * KHG_NBINS + (size_t)(v + KHG_SYM_BIAS);
+            if (ws.hist_cnt[bin]++ == 0) ws.hist_first[bin] = (uint32_t)i;
+        }
+    }
+    KhgTableArgs t = khg_table_args(ws);
+    KhgTableSmem* tsh = new KhgTableSmem;
+    for (int p = 0; p < 3; ++p) khg_table_body(t, p, *tsh);
+    delete tsh;
+    KhgEncArgs e = khg_enc_args(ws, rows, cols, lvl, out, cap);
+    sim_pack_single_pass(e);
+    if (out_len) *out_len = (size_t)ws.res->total_len;
+    return ws.res->status;
+}
+
 int khgsim_encode_indexed(const uint8_t* r, const uint8_t* g, const uint8_t* b, int rows, int cols, int lvl,
                           uint8_t* out, size_t cap, size_t* out_len) {
     if (!khg_dims_ok(rows, cols) || lvl < 0 || lvl > 2) return -1;

@@ -111,6 +111,19 @@ def encode(rgb, lvl, cap=None):
     return rc, out[:n.value].tobytes() if rc == 0 else b""
 
 
+def pack_symbols(qy, qcb, qcr, lvl):
+    """The entropy coder alone (table, single-pass packer, header) on the caller's int16 symbol planes."""
+    h, w = qy.shape
+    cap = (36 + h * w * 12 + 3 * 16384 * 8 + 3) // 4 * 4
+    out = np.zeros(cap, np.uint8)
+    n = C.c_size_t(0)
+    q = [np.ascontiguousarray(a, np.int16) for a in (qy, qcb, qcr)]
+    L = lib()
+    L.khgsim_pack_symbols.argtypes = [C.c_void_p] * 3 + [C.c_int] * 3 + [_u8p, C.c_size_t, C.POINTER(C.c_size_t)]
+    rc = L.khgsim_pack_symbols(q[0].ctypes.data, q[1].ctypes.data, q[2].ctypes.data, h, w, lvl, out, cap, C.byref(n))
+    return rc, out[:n.value].tobytes() if rc == 0 else b""
+
+
 def bgr_pixels(rgb):
     """The pixel array of the 24-bit BMP that holds `rgb` ((3, H, W) u8): B, G, R per pixel, rows bottom-up, rows
     padded to a multiple of 4 bytes (pad bytes filled with 0xAA: nothing may depend on them)."""

@@ -72,6 +72,71 @@ def test_single_pass_packer_on_noise(lvl):
     assert rc == 0 and comp == O.encode(rgb, lvl)
 
 
+def _file_from_symbols(planes, rows, cols, lvl):
+    """The .comp file of given symbol planes, put together here from the oracle's table and codes (Huffman.h:57-139,
+    Writer.h:9-69): header, the three streams MSB first and zero-padded to a byte, the tables."""
+    import struct
+    streams, tables, lens_bits, pads, ks, longest = [], [], [], [], [], 0
+    for q in planes:
+        q = np.ascontiguousarray(q, np.int32).ravel()
+        counts, syms = O.symbol_table(q)
+        codes, lens = O.build_codes(counts, syms)
+        order = np.argsort(syms, kind="stable")
+        at = order[np.searchsorted(syms[order], q)]
+        ln = lens[at].astype(np.int64)
+        cd = codes[at]
+        start = np.cumsum(ln) - ln
+        total = int(ln.sum())
+        idx = np.repeat(np.arange(q.size), ln)
+        k = np.arange(total) - np.repeat(start, ln)
+        bits = ((cd[idx] >> (ln[idx] - 1 - k).astype(np.uint64)) & np.uint64(1)).astype(np.uint8)
+        pad = (8 - total % 8) % 8
+        streams.append(np.packbits(np.concatenate([bits, np.zeros(pad, np.uint8)])).tobytes())
+        tables.append(b"".join(struct.pack("<ii", int(c), int(v)) for c, v in zip(counts, syms)))
+        lens_bits.append(total + pad)
+        pads.append(pad)
+        ks.append(len(counts))
+        longest = max(longest, int(lens.max()))
+    head = struct.pack("<8i4B", *lens_bits, *ks, rows, cols, *pads, lvl)
+    return head + b"".join(streams) + b"".join(tables), longest
+
+
+def test_entropy_coder_on_given_symbols_matches_the_oracle_file():
+    """Checks the helper above (and the simulator's symbol-plane entry) against a whole oracle file."""
+    rgb = synth_frame(64, 96, 3, 1)
+    q = O.symbols(rgb, 1)
+    want, _ = _file_from_symbols(q, 64, 96, 1)
+    assert want == O.encode(rgb, 1)
+    rc, comp = S.pack_symbols(*[a.astype(np.int16) for a in q], 1)
+    assert rc == 0 and comp == want
+
+
+def test_single_pass_packer_with_pairs_beyond_56_bits():
+    """Counts that follow the Fibonacci numbers give the deepest tree a table of 30 symbols can have: the two rarest
+    symbols, -8 and 7, get 29-bit codes, so their pair has no joint entry in the packer's pair table (58 bits), other
+    pairs of long codes have, threads string more than 64 bits together, and symbols outside -8 .. 7 sit beside
+    them."""
+    rows, cols = 1024, 2304
+    n = rows * cols
+    vals = [-8, 7, -7, 6, -6, 5, -5, 4, -4, 3, -3, 2, -2, 1, -1, 0] + list(range(8, 22))  # rarest first
+    fib = [1, 1]
+    while len(fib) < len(vals):
+        fib.append(fib[-1] + fib[-2])
+    assert sum(fib) <= n
+    rng = np.random.default_rng(11)
+    body = np.repeat(np.array(vals[2:], np.int16), fib[2:])
+    body = np.concatenate([body, np.full(n - 2 - body.size, vals[-1], np.int16)])
+    rng.shuffle(body)
+    qy = np.concatenate([body[:16], np.array([-8, 7], np.int16), body[16:]]).reshape(rows, cols)  # an aligned pair
+    qc = rng.integers(-3, 4, (2, rows // 2, cols // 2)).astype(np.int16)
+    want, longest = _file_from_symbols([qy, qc[0], qc[1]], rows, cols, 1)
+    assert longest == 29
+    rc, comp = S.pack_symbols(qy, qc[0], qc[1], 1)
+    assert rc == 0 and comp == want
+    rc, out, q, _ = S.decode(comp, rows, cols)  # 29-bit codes: beyond both decode tables
+    assert rc == 0 and np.array_equal(q[0], qy) and np.array_equal(out, O.decode(comp))
+
+
 @pytest.mark.parametrize("name,lvl", [("cat", 1), ("couple", 0), ("library", 2), ("lena", 1), ("baboon", 0)])
 def test_run_images(run_images, name, lvl):
     rgb = run_images[name]
