@@ -33,6 +33,8 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--virtual", type=int, default=0, help="rehearse this many ranks on one GPU (threads)")
+    ap.add_argument("--merge", choices=("reduce", "gather"), default="reduce",
+                    help="how the ranks' shares become the file (khugle_amd.tiled.encode_tiled)")
     ap.add_argument("--gpus", type=int, default=0,
                     help="ranks (one process per GPU); started plainly, this process launches them itself")
     args = ap.parse_args()
@@ -69,7 +71,7 @@ def main():
                 dist.barrier()
             torch.cuda.synchronize()
             a = time.perf_counter()
-            comp = tiled.encode_tiled(be, strip, side, side, LVL, r, w, coll=coll)
+            comp = tiled.encode_tiled(be, strip, side, side, LVL, r, w, coll=coll, merge=args.merge)
             torch.cuda.synchronize()
             b = time.perf_counter()
             # the file goes back to every rank (decode needs the whole stream)
@@ -157,7 +159,7 @@ def main():
             "value": round(mp / (t_enc + t_dec), 1), "unit": "MP/s", "n_gpus": world, "tiles": nranks, "mode": mode,
             "steps": args.steps, "warmup": args.warmup, "encode_mp_s": round(mp / t_enc, 1),
             "decode_mp_s": round(mp / t_dec, 1), "comp_bytes": comp_len,
-            "bits_per_pixel": round(8.0 * comp_len / px, 4), "identical_to_single_tile": ok,
+            "bits_per_pixel": round(8.0 * comp_len / px, 4), "identical_to_single_tile": ok, "merge": args.merge,
             "scaling": "strong", "data": "synthetic", "dtype": "f64"}), flush=True)
     if world > 1:
         dist.barrier()

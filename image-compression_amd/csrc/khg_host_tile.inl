@@ -99,6 +99,16 @@ extern "C" int khg_tile_bits_get(khg_ctx* c, uint32_t* d_bits, void* stream)
     return khg_end(c, (hipStream_t)stream, 0);
 }
 
+extern "C" int khg_tile_chunk_off_get(khg_ctx* c, uint64_t* d_off, void* stream)
+{
+    if (!c || !d_off || c->tile.nranks < 1) return KHG_ERR_ARG;
+    size_t n = khg_tile_chunk_count(c->tile_rows, c->tile_cols, c->tile.nranks);
+    int rc = khg_begin(c, (hipStream_t)stream);
+    if (rc) return rc;
+    KHG_HIP(hipMemcpyAsync(d_off, c->ws.chunk_off, n * 8, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return khg_end(c, (hipStream_t)stream, 0);
+}
+
 extern "C" int khg_tile_bits_set(khg_ctx* c, const uint32_t* d_bits, void* stream)
 {
     if (!c || !d_bits || c->tile.nranks < 1) return KHG_ERR_ARG;

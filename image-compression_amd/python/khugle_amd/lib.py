@@ -74,6 +74,7 @@ SYMBOLS = [
     ("khg_tile_hist_set", C.c_int, [_P, _P, _P, _P]),
     ("khg_tile_lens_dev", C.c_int, [_P, _P]),
     ("khg_tile_bits_get", C.c_int, [_P, _P, _P]),
+    ("khg_tile_chunk_off_get", C.c_int, [_P, _P, _P]),
     ("khg_tile_bits_set", C.c_int, [_P, _P, _P]),
     ("khg_tile_pack_dev", C.c_int, [_P, _P, C.c_size_t, _P]),
     ("khg_tile_decode_dev", C.c_int, [_P, _P, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P]),

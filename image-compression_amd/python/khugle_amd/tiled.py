@@ -101,6 +101,12 @@ class HipTileBackend:
     def bits_set(self, bits):
         _check(self.L.khg_tile_bits_set(self.c._ctx, _ptr(bits), _stream()), "tile_bits_set")
 
+    def chunk_off_get(self):
+        rows, cols, world = self.shape
+        off = torch.empty(self.L.khg_tile_chunk_count(rows, cols, world), dtype=torch.int64, device=self.dev)
+        _check(self.L.khg_tile_chunk_off_get(self.c._ctx, _ptr(off), _stream()), "tile_chunk_off_get")
+        return off
+
     def pack(self, cap):
         share = torch.empty(cap, dtype=torch.uint8, device=self.dev)
         _check(self.L.khg_tile_pack_dev(self.c._ctx, _ptr(share), cap, _stream()), "tile_pack")
@@ -199,9 +205,73 @@ class DistCollectives:
                 req.wait()
 
 
-def encode_tiled(backend, strip, rows, cols, lvl, rank, world, coll=None, dst=0):
+def _word_runs(sel, w0, w1, head=None, tail=None):
+    """Word ranges [s, e) of the file that the chunks picked by `sel` touch: one per stretch of consecutive picked
+    chunks, in file order, cut so that no word appears twice.  head / tail: a range put in front / behind."""
+    prev = torch.zeros_like(sel)
+    prev[1:] = sel[:-1]
+    nxt = torch.zeros_like(sel)
+    nxt[:-1] = sel[1:]
+    s, e = w0[sel & ~prev], w1[sel & ~nxt]
+    if head is not None:
+        s, e = torch.cat([s.new_tensor([head[0]]), s]), torch.cat([e.new_tensor([head[1]]), e])
+    if tail is not None:
+        s, e = torch.cat([s, s.new_tensor([tail[0]])]), torch.cat([e, e.new_tensor([tail[1]])])
+    if s.numel():
+        before = torch.cat([e.new_zeros(1), e[:-1]])  # two stretches of one rank can meet in a word
+        s = torch.maximum(s, before)
+    keep = e > s
+    return s[keep], e[keep]
+
+
+def _run_words(s, e):
+    """The word indices of the ranges [s, e), in order."""
+    lens = e - s
+    total = int(lens.sum().item()) if lens.numel() else 0
+    if total == 0:
+        return torch.zeros(0, dtype=torch.int64, device=s.device)
+    first = torch.cumsum(lens, 0) - lens
+    return torch.repeat_interleave(s - first, lens) + torch.arange(total, dtype=torch.int64, device=s.device)
+
+
+def gather_shares(words, own, bits, off, rank, world, coll, dst):
+    """The file from the ranks' shares with every byte moved once.  words: this rank's share as int32 words (zero
+    where it owns nothing); own: which chunks are this rank's; bits, off: every chunk's bit count and bit offset
+    in the file (the same on all ranks).  A rank sends the words its chunks touch -- rank 0 also the header's and the
+    tables' -- and `dst` adds what it receives in place: where two ranks' chunks meet inside a word both send it,
+    and their bits are disjoint.  Returns the words of the file on `dst`, None elsewhere."""
+    nwords = words.numel()
+    filled = bits > 0
+    owner = torch.where(own & filled, torch.full_like(bits, rank + 1), torch.zeros_like(bits))
+    coll.reduce_sum(owner, dst)  # chunk -> rank + 1 (only dst looks at it)
+    w0 = off >> 5
+    w1 = (off + bits.to(torch.int64) + 31) >> 5
+    stream_end = int((off + bits.to(torch.int64)).max().item()) if bits.numel() else 36 * 8
+
+    def indices(r, sel):
+        head = (0, 9) if r == 0 else None  # Writer.h:9-23: the 36-byte header
+        tail = (stream_end >> 5, nwords) if r == 0 else None  # the streams' last word, pad bits, tables
+        return _run_words(*_word_runs(sel, w0, w1, head, tail))
+
+    if rank != dst:
+        idx = indices(rank, own & filled)
+        coll.exchange([(dst, words[idx].contiguous())], [])
+        return None
+    idxs = [indices(r, (owner == r + 1) if r != rank else (own & filled)) for r in range(world)]
+    bufs = [torch.empty(idxs[r].numel(), dtype=words.dtype, device=words.device) for r in range(world)]
+    coll.exchange([], [(r, bufs[r]) for r in range(world) if r != rank])
+    out = torch.zeros_like(words)
+    for r in range(world):
+        out.index_add_(0, idxs[r], words[idxs[r]] if r == rank else bufs[r])
+    return out
+
+
+def encode_tiled(backend, strip, rows, cols, lvl, rank, world, coll=None, dst=0, merge="reduce"):
     """All ranks call this with their strip (image rows input_rows(rows, rank, world)).  Returns the bytes of the
-    .comp file as a uint8 tensor on rank `dst` (None elsewhere) -- the same bytes a single GPU produces."""
+    .comp file as a uint8 tensor on rank `dst` (None elsewhere) -- the same bytes a single GPU produces.
+    merge: "reduce" adds the ranks' whole zero-padded shares up in one collective of the file's size; "gather" moves
+    every byte of the file once, point to point (gather_shares: an eighth of the link traffic on eight ranks, paid
+    for with index arithmetic on every rank)."""
     coll = coll or DistCollectives()
     backend.forward(strip, rows, cols, lvl, rank, world)
     cnt, first = backend.hist_get()
@@ -214,6 +284,7 @@ def encode_tiled(backend, strip, rows, cols, lvl, rank, world, coll=None, dst=0)
     backend.hist_set(cnt, first)
     backend.lens()
     bits = backend.bits_get()
+    own = bits != 0  # before the all-reduce only this rank's chunks have a bit count
     coll.all_reduce_sum(bits)
     backend.bits_set(bits)
     share, total, status = backend.pack(backend.comp_bound(rows, cols))
@@ -226,7 +297,10 @@ def encode_tiled(backend, strip, rows, cols, lvl, rank, world, coll=None, dst=0)
     if worst != 0:
         raise _lib.KhgError(worst, "encode_tiled (rank %d saw status %d)" % (rank, status))
     words = share[: (total + 3) & ~3].view(torch.int32)
-    coll.reduce_sum(words, dst)  # the shares have no set bit in common: their sum is their OR
+    if merge == "gather":
+        words = gather_shares(words, own, bits, backend.chunk_off_get(), rank, world, coll, dst)
+    else:
+        coll.reduce_sum(words, dst)  # the shares have no set bit in common: their sum is their OR
     if rank != dst:
         return None
     return words.view(torch.uint8)[:total]

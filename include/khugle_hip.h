@@ -227,7 +227,11 @@ int khg_batch_decode(khg_batch *b, int n, const uint8_t *const *comp, const size
  *   4. khg_tile_bits_get  ->  all-reduce SUM over khg_tile_chunk_count words  ->  khg_tile_bits_set
  *   5. khg_tile_pack_dev      this rank's share of the .comp bytes at their final positions, zero elsewhere
  *                             (rank 0's share holds the header and tables); khg_encode_result: status, file length
- *   6. reduce SUM (or OR) of the shares as 32-bit words to the rank that keeps the file.
+ *   6. reduce SUM (or OR) of the shares as 32-bit words to the rank that keeps the file -- or, moving each byte
+ *      once: khg_tile_chunk_off_get gives every chunk's bit offset in the file (the same on all ranks after step
+ *      5), a rank's chunks are the ones whose bits were non-zero before step 4's all-reduce, so each rank sends the
+ *      32-bit words its chunks touch and the keeper adds them in place (a word shared by two ranks' chunks gets
+ *      both contributions: their bits are disjoint).
  * khg_tile_decode_dev: every rank decodes the whole stream and reconstructs its own rows (Decompress.h:7-126 on
  * the tile); d_r/d_g/d_b receive exactly the tile's rows. */
 int khg_tile_input_rows(int rows, int rank, int nranks, int *row0, int *row1);
@@ -240,6 +244,7 @@ int khg_tile_lens_dev(khg_ctx *ctx, void *stream);
 int khg_tile_bits_get(khg_ctx *ctx, uint32_t *d_bits, void *stream);
 int khg_tile_bits_set(khg_ctx *ctx, const uint32_t *d_bits, void *stream);
 int khg_tile_pack_dev(khg_ctx *ctx, uint8_t *d_out, size_t cap, void *stream);
+int khg_tile_chunk_off_get(khg_ctx *ctx, uint64_t *d_bit_offsets, void *stream);
 int khg_tile_decode_dev(khg_ctx *ctx, const uint8_t *d_comp, size_t len, int rows, int cols, int rank, int nranks,
                         uint8_t *d_r, uint8_t *d_g, uint8_t *d_b, void *stream);
 

@@ -461,6 +461,11 @@ void khgsim_tile_bits_get(void* h, uint32_t* bits) {
     memcpy(bits, T->S.ws.chunk_bits, khgsim_tile_chunk_count(T->rows, T->cols, T->t.nranks) * 4);
 }
 
+void khgsim_tile_chunk_off_get(void* h, uint64_t* off) {
+    SimTile* T = (SimTile*)h;
+    memcpy(off, T->S.ws.chunk_off, khgsim_tile_chunk_count(T->rows, T->cols, T->t.nranks) * 8);
+}
+
 void khgsim_tile_bits_set(void* h, const uint32_t* bits) {
     SimTile* T = (SimTile*)h;
     memcpy(T->S.ws.chunk_bits, bits, khgsim_tile_chunk_count(T->rows, T->cols, T->t.nranks) * 4);

@@ -82,7 +82,7 @@ def lib():
             getattr(L, "khgsim_tile_" + f).restype = None
         L.khgsim_tile_lens.argtypes = [_vp]
         L.khgsim_tile_lens.restype = None
-        for f in ("bits_get", "bits_set"):
+        for f in ("bits_get", "bits_set", "chunk_off_get"):
             getattr(L, "khgsim_tile_" + f).argtypes = [_vp, _vp]
             getattr(L, "khgsim_tile_" + f).restype = None
         L.khgsim_tile_pack.argtypes = [_vp, _vp, C.c_size_t, C.POINTER(C.c_size_t)]
@@ -353,6 +353,11 @@ class SimTileBackend:
 
     def bits_set(self, bits):
         lib().khgsim_tile_bits_set(self.h, bits.contiguous().data_ptr())
+
+    def chunk_off_get(self):
+        off = self.torch.empty(lib().khgsim_tile_chunk_count(self.rows, self.cols, self.world), dtype=self.torch.int64)
+        lib().khgsim_tile_chunk_off_get(self.h, off.data_ptr())
+        return off
 
     def pack(self, cap):
         share = self.torch.empty(cap, dtype=self.torch.uint8)

@@ -61,6 +61,32 @@ def test_tiles_give_the_bytes_of_one_encoder(shape, world, lvl):
         assert np.array_equal(tile, full[:, r0:r1]), rank
 
 
+@pytest.mark.parametrize("merge,dst", [("reduce", 0), ("gather", 1), ("gather", 3)])
+def test_file_merge_by_reduce_and_by_gather(merge, dst):
+    """The ranks' shares become the file either by one reduce of the whole zero-padded shares or by sending each
+    rank's words once to the rank that keeps the file (any rank; the header and tables come from rank 0).  Half rows
+    of 36 and 68 symbols: most chunks are shorter than a word, so stretches of one rank meet stretches of others,
+    and of itself, inside words."""
+    from khugle_amd import tiled
+    from khugle_amd.synth import synth_frame
+    import oracle_py as O
+    import simlib as S
+    from tiledlib import run_ranks
+    rows, cols, world, lvl = 128, 72, 4, 1
+    rgb = synth_frame(rows, cols, 5, 2)
+    want = O.encode(rgb, lvl)
+
+    def rank_fn(rank, coll):
+        be = S.SimTileBackend(rows, cols)
+        comp = tiled.encode_tiled(be, _strip(rgb, rows, rank, world), rows, cols, lvl, rank, world, coll=coll, dst=dst,
+                                  merge=merge)
+        return None if comp is None else comp.numpy().tobytes()
+
+    res = run_ranks(world, rank_fn)
+    assert res[dst] == want
+    assert all(r is None for i, r in enumerate(res) if i != dst)
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -83,11 +109,16 @@ def _gloo_rank(rank, world, port, rows, cols, lvl, out_path):
     i0, i1 = tiled.input_rows(rows, rank, world)
     assert np.array_equal(strip.numpy(), rgb[:, i0:i1])
     comp = tiled.encode_tiled(S.SimTileBackend(rows, cols), strip, rows, cols, lvl, rank, world)
+    # the same file with every byte sent once, point to point, to rank 1 (the other merge of the shares)
+    again = tiled.encode_tiled(S.SimTileBackend(rows, cols), strip, rows, cols, lvl, rank, world, dst=1, merge="gather")
     if rank == 0:
+        assert again is None
         with open(out_path, "wb") as f:
             f.write(comp.numpy().tobytes())
     else:
         assert comp is None
+        with open(out_path + ".gathered", "wb") as f:
+            f.write(again.numpy().tobytes())
     # decode over the same ranks: the file goes to every rank, each entropy-decodes half of every plane's stream,
     # the workgroup records are all-reduced and the symbols travel point to point
     length = torch.tensor([comp.numel() if rank == 0 else 0], dtype=torch.int64)
@@ -112,6 +143,7 @@ def test_two_gloo_ranks_exchange_halos_and_histograms(tmp_path):
     from khugle_amd.synth import synth_frame
     want = O.encode(synth_frame(rows, cols, 11, 0), lvl)
     assert open(out, "rb").read() == want
+    assert open(out + ".gathered", "rb").read() == want
     pixels = O.decode(want)
     for rank in range(world):
         r0, r1 = tiled.tile_rows(rows, rank, world)
