@@ -44,6 +44,17 @@ def test_tiles_on_one_gpu_give_the_bytes_of_one_encoder(codec, shape, world, lvl
     res = run_ranks(world, rank_fn)
     assert res[0] == want
     assert all(r is None for r in res[1:])
+
+    def gather_fn(rank, coll):  # the other merge of the shares: every byte sent once, to the last rank
+        be = tiled.HipTileBackend(ctxs[rank])
+        comp = tiled.encode_tiled(be, _strip(frame, rows, rank, world), rows, cols, lvl, rank, world, coll=coll,
+                                  dst=world - 1, merge="gather")
+        torch.cuda.synchronize()
+        return None if comp is None else comp.cpu().numpy().tobytes()
+
+    res = run_ranks(world, gather_fn)
+    assert res[world - 1] == want
+    assert all(r is None for r in res[:-1])
     comp_t = torch.from_numpy(np.frombuffer(want + b"\0" * 8, np.uint8).copy()).cuda()
     for rank in range(world):  # every rank decodes the whole stream
         tile = tiled.decode_tiled(tiled.HipTileBackend(ctxs[rank]), comp_t, len(want), rows, cols, rank, world,
