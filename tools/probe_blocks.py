@@ -6,6 +6,10 @@ import sys
 import numpy as np
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "image-compression_amd", "python"))
+import khugle_amd.lib
+
+if os.environ.get("KHG_LIB"):  # the KHG_TIMING build of the library
+    khugle_amd.lib.LIB_PATH = os.environ["KHG_LIB"]
 import torch
 from khugle_amd import Codec
 from khugle_amd import lib as L
