@@ -67,6 +67,7 @@ KHG_DEV KhgIdxPlace khg_idx_place(const KhgEncArgs& a, uint64_t v1_len)
 struct KhgIdxSmem {
     uint64_t hot[KHG_HOT_SYMS];
     uint32_t wave[KHG_SUPER][4];
+    uint16_t pairlen[256];  // the two code lengths of a pair of symbols in -8 .. 7 (index as in khg_pair_entry); 0: no entry
 };
 
 // One workgroup per entry of the packer's chain (khg_chain_entry: 8 chunks of 2048 symbols), after khg_packscan_body
@@ -97,7 +98,13 @@ KHG_DEV void khg_index_body(const KhgEncArgs& a, uint32_t t, KhgIdxSmem& sh)
     uint64_t lens[KHG_SUPER][KHG_NSLOT(256)];  // code lengths of a thread's eight symbols, a byte each
     uint32_t tbs[KHG_SUPER][KHG_NSLOT(256)], excl[KHG_SUPER][KHG_NSLOT(256)];
     int nvs[KHG_SUPER][KHG_NSLOT(256)];
-    KHG_FOR_THREADS(256) { sh.hot[tid] = ctab[KHG_SYM_BIAS - KHG_HOT_SYMS / 2 + tid]; }
+    KHG_FOR_THREADS(256)
+    {
+        sh.hot[tid] = ctab[KHG_SYM_BIAS - KHG_HOT_SYMS / 2 + tid];
+        const int q0 = (int)(((uint32_t)tid & 15u) ^ 8u) - 8, q1 = (int)((((uint32_t)tid >> 4) & 15u) ^ 8u) - 8;
+        const uint32_t l0 = (uint32_t)(ctab[q0 + KHG_SYM_BIAS] >> 56), l1 = (uint32_t)(ctab[q1 + KHG_SYM_BIAS] >> 56);
+        sh.pairlen[tid] = (l0 && l1) ? (uint16_t)(l0 | (l1 << 8)) : (uint16_t)0;
+    }
     KHG_BARRIER();
     KHG_FOR_THREADS(256)
     {
@@ -107,11 +114,28 @@ KHG_DEV void khg_index_body(const KhgEncArgs& a, uint32_t t, KhgIdxSmem& sh)
             const int nv = s0 >= en.sym1 ? 0 : khg_load8(a.sym[p], s0, en.sym1, v);
             uint32_t tb = 0;
             uint64_t lv = 0;
-            for (int i = 0; i < 8; ++i) {
-                if (i < nv) {
-                    const uint32_t len = (uint32_t)(khg_pack_code_lds(sh.hot, ctab, v[i]) >> 56);
-                    lv |= (uint64_t)len << (8 * i);
-                    tb += len;
+            // two symbols per lookup, as in the packer; `odd`: a symbol outside -8 .. 7, a pair without an entry, a
+            // ragged end
+            uint32_t w[4] = {0, 0, 0, 0};
+            if (nv == 8) __builtin_memcpy(w, v, 16);
+            uint32_t odd = nv == 8 ? 0u : 1u;
+            KHG_UNROLL
+            for (int q = 0; q < 4; ++q) {
+                odd |= (w[q] ^ (w[q] << 1)) & 0xFFF0FFF0u;
+                const uint32_t e = sh.pairlen[(w[q] & 15u) | ((w[q] >> 12) & 0xF0u)];
+                odd |= e == 0;
+                lv |= (uint64_t)e << (16 * q);
+                tb += (e & 255u) + (e >> 8);
+            }
+            if (odd) {
+                tb = 0;
+                lv = 0;
+                for (int i = 0; i < 8; ++i) {
+                    if (i < nv) {
+                        const uint32_t len = (uint32_t)(khg_pack_code_lds(sh.hot, ctab, v[i]) >> 56);
+                        lv |= (uint64_t)len << (8 * i);
+                        tb += len;
+                    }
                 }
             }
             lens[j][KHG_SLOT] = lv;
@@ -120,8 +144,8 @@ KHG_DEV void khg_index_body(const KhgEncArgs& a, uint32_t t, KhgIdxSmem& sh)
         }
     }
     uint32_t tot[KHG_SUPER], sub_base[KHG_SUPER], total = 0;
+    KHG_WG_EXCL_SCAN_N(KHG_SUPER, excl, tbs, sh.wave, tot)
     for (int j = 0; j < KHG_SUPER; ++j) {
-        KHG_WG_EXCL_SCAN(excl[j], tbs[j], sh.wave[j], tot[j])
         sub_base[j] = total;
         total += tot[j];
     }
@@ -135,6 +159,8 @@ KHG_DEV void khg_index_body(const KhgEncArgs& a, uint32_t t, KhgIdxSmem& sh)
             uint64_t b = rel0 + sub_base[j] + excl[j][KHG_SLOT];
             const uint32_t s0 = en.sym0 + (uint32_t)j * KHG_CHUNK + (uint32_t)tid * 8;
             const uint64_t lv = lens[j][KHG_SLOT];
+            // nearly always none of the thread's codewords reaches a multiple of KHG_SUB_BITS
+            if (b / KHG_SUB_BITS == (b + tbs[j][KHG_SLOT]) / KHG_SUB_BITS) continue;
             for (int i = 0; i < nvs[j][KHG_SLOT]; ++i) {
                 const uint64_t e = b + ((lv >> (8 * i)) & 255u);
                 const uint64_t s = e / KHG_SUB_BITS;
