@@ -24,6 +24,7 @@
 #define KHG_TOUCH_DONE(reg) ((void)(reg))
 #define KHG_UNROLL
 #define KHG_NOUNROLL
+#define KHG_ASSUME_ALIGNED(p, n) (p)  // the simulator's buffers are not aligned like the device workspace
 // Workgroup collective (256 threads, like KHG_BARRIER not inside KHG_FOR_THREADS): excl[t] = val[0] + .. + val[t-1],
 // total = the sum of all; lds4: four LDS words nobody else touches until the next barrier.
 #define KHG_WG_EXCL_SCAN(excl, val, lds4, total)   \
@@ -36,10 +37,27 @@
         }                                          \
         (total) = run_;                            \
     }
+// The same for a workgroup of NW waves: lds: NW words nobody else touches until the next barrier.
+#define KHG_WG_EXCL_SCAN_NW(NW, excl, val, lds, total) \
+    {                                                  \
+        uint32_t run_ = 0;                             \
+        for (int t_ = 0; t_ < 64 * (NW); ++t_) {       \
+            const uint32_t v_ = (val)[t_];             \
+            (excl)[t_] = run_;                         \
+            run_ += v_;                                \
+        }                                              \
+        (void)(lds);                                   \
+        (total) = run_;                                \
+    }
 // N such scans behind one barrier: excl[j][t], val[j][t], lds[j][4], total[j] for j < N.
 #define KHG_WG_EXCL_SCAN_N(N, excl, val, lds, total)                                           \
     {                                                                                          \
         for (int j_ = 0; j_ < (N); ++j_) KHG_WG_EXCL_SCAN((excl)[j_], (val)[j_], (lds)[j_], (total)[j_]) \
+    }
+// ... and for a workgroup of NW waves (lds[j][NW]).
+#define KHG_WG_EXCL_SCAN_N_NW(N, NW, excl, val, lds, total)                                    \
+    {                                                                                          \
+        for (int j_ = 0; j_ < (N); ++j_) KHG_WG_EXCL_SCAN_NW(NW, (excl)[j_], (val)[j_], (lds)[j_], (total)[j_]) \
     }
 // Workgroup collective (NW waves, not inside KHG_FOR_THREADS): the sums of two doubles over all threads, to every
 // thread, for values whose sum does not depend on the order (integers below 2^53).  lds: a KhgWgSum2 nobody else
@@ -86,6 +104,7 @@ static inline void khg_chain_store(uint64_t* p, uint64_t v) { *p = v; }
 #define KHG_TOUCH_DONE(reg) asm volatile("s_waitcnt vmcnt(0)" : "+v"(reg) : : "memory")
 #define KHG_UNROLL _Pragma("unroll")
 #define KHG_NOUNROLL _Pragma("nounroll")
+#define KHG_ASSUME_ALIGNED(p, n) __builtin_assume_aligned(p, n)
 // Inclusive prefix sum over the lanes of a wave.
 // v + (v of the lanes the DPP control names); lanes without a source (shifted in from outside a row, or excluded by
 // the row mask) add zero.
@@ -124,8 +143,25 @@ __device__ __forceinline__ uint32_t khg_wave_incl_scan(uint32_t v)
         (excl)[0] = base_ + inc_ - (val)[0];                          \
         (total) = tot_;                                               \
     }
-// N such scans behind one barrier: excl[j][0], val[j][0], lds[j][4], total[j] for j < N.
-#define KHG_WG_EXCL_SCAN_N(N, excl, val, lds, total)                               \
+// The same for a workgroup of NW waves: lds: NW words nobody else touches until the next barrier.
+#define KHG_WG_EXCL_SCAN_NW(NW, excl, val, lds, total)                \
+    {                                                                 \
+        const uint32_t inc_ = khg_wave_incl_scan((val)[0]);           \
+        const uint32_t w_ = threadIdx.x >> 6;                         \
+        if ((threadIdx.x & 63u) == 63u) (lds)[w_] = inc_;             \
+        __syncthreads();                                              \
+        uint32_t base_ = 0, tot_ = 0;                                 \
+        _Pragma("unroll") for (uint32_t i_ = 0; i_ < (NW); ++i_)     \
+        {                                                             \
+            const uint32_t s_ = (lds)[i_];                            \
+            base_ += i_ < w_ ? s_ : 0u;                               \
+            tot_ += s_;                                               \
+        }                                                             \
+        (excl)[0] = base_ + inc_ - (val)[0];                          \
+        (total) = tot_;                                               \
+    }
+// N such scans behind one barrier, for a workgroup of NW waves: excl[j][0], val[j][0], lds[j][NW], total[j] for j < N.
+#define KHG_WG_EXCL_SCAN_N_NW(N, NW, excl, val, lds, total)                        \
     {                                                                              \
         uint32_t inc_[N];                                                          \
         const uint32_t w_ = threadIdx.x >> 6;                                      \
@@ -138,7 +174,7 @@ __device__ __forceinline__ uint32_t khg_wave_incl_scan(uint32_t v)
         _Pragma("unroll") for (int j_ = 0; j_ < (N); ++j_)                        \
         {                                                                          \
             uint32_t base_ = 0, tot_ = 0;                                          \
-            _Pragma("unroll") for (uint32_t i_ = 0; i_ < 4; ++i_)                 \
+            _Pragma("unroll") for (uint32_t i_ = 0; i_ < (NW); ++i_)              \
             {                                                                      \
                 const uint32_t s_ = (lds)[j_][i_];                                 \
                 base_ += i_ < w_ ? s_ : 0u;                                        \
@@ -148,6 +184,7 @@ __device__ __forceinline__ uint32_t khg_wave_incl_scan(uint32_t v)
             (total)[j_] = tot_;                                                    \
         }                                                                          \
     }
+#define KHG_WG_EXCL_SCAN_N(N, excl, val, lds, total) KHG_WG_EXCL_SCAN_N_NW(N, 4, excl, val, lds, total)
 // v + (v of the lanes the DPP control names); lanes the row mask excludes add zero.
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double khg_dpp_add(double v)

@@ -447,10 +447,8 @@ KHG_DEV void khg_lens_body(const KhgEncArgs& a, uint32_t chunk, KhgLensSmem& sh)
 }
 
 struct KhgScanSmem {
-    uint64_t psum[3][1024];
-    uint64_t grp[3][32];  // running totals of groups of 32 threads
-    uint64_t base[3];     // bit offset of each plane's stream in the file
-    uint64_t table_off;   // byte offset of the tables
+    uint32_t wave[2][16];  // wave totals of the workgroup scan, alternating between the tiles of chunks
+    uint64_t table_off;    // byte offset of the tables
     int ok;
 };
 
@@ -466,69 +464,82 @@ KHG_DEV void khg_store_le32(uint8_t* p, int32_t v)
 // Single workgroup, 1024 threads.
 KHG_DEV void khg_scan_body(const KhgEncArgs& a, KhgScanSmem& sh)
 {
-    const uint32_t per = (a.nchunks + 1023) / 1024;
-    KHG_FOR_THREADS(1024)
-    {
-        uint64_t s[3] = {0, 0, 0};
-        uint32_t c0 = (uint32_t)tid * per, c1 = c0 + per < a.nchunks ? c0 + per : a.nchunks;
-        for (uint32_t c = c0; c < c1; c += 8) {  // eight loads in flight at a time
-            uint32_t v[8];
-            KHG_UNROLL
-            for (int i = 0; i < 8; ++i) v[i] = c + i < c1 ? a.chunk_bits[c + i] : 0;
-            KHG_UNROLL
-            for (int i = 0; i < 8; ++i)
-                if (c + i < c1) s[khg_chunk_plane(a, c + i)] += v[i];
-        }
-        for (int p = 0; p < 3; ++p) sh.psum[p][tid] = s[p];
-    }
-    KHG_BARRIER();
-    KHG_FOR_THREADS(1024)
-    {
-        // exclusive scan of the 1024 per-thread sums in two short serial steps: inside groups of 32 threads ...
-        if (tid < 96) {
-            const int p = tid >> 5, g = tid & 31;
-            uint64_t run = 0;
-            for (int i = 0; i < 32; ++i) {
-                uint64_t v = sh.psum[p][g * 32 + i];
-                sh.psum[p][g * 32 + i] = run;
-                run += v;
+    // One pass over the chunk bit counts, plane after plane, 8192 chunks (eight consecutive ones per thread) at a
+    // time: a workgroup scan gives every chunk its offset behind the bits counted so far, and a plane's padded length
+    // is known when its last chunk is (so is where the next plane begins).  The packer ORs the words that chunks
+    // share into the output: the caller hands over a zeroed buffer (khg_tile_pack_dev fills it before this launch).
+    uint64_t off = 36 * 8;  // Writer.h:9-23: the streams start behind the 36-byte header
+    bool ok = true;
+    uint32_t it = 0;
+    for (int p = 0; p < 3; ++p) {
+        const uint32_t c_begin = a.chunk0[p], c_end = p < 2 ? a.chunk0[p + 1] : a.nchunks;
+        uint64_t run = 0;  // the plane's bits so far
+        // tiles begin at multiples of eight chunks, so a thread's eight counts are one aligned 32-byte load and its
+        // eight offsets one aligned 64-byte store (chunks of the plane before, in the first tile, count as empty)
+        for (uint32_t tb = c_begin & ~7u; tb < c_end; tb += 8192, ++it) {
+            uint32_t v[KHG_NSLOT(1024)][8], sum[KHG_NSLOT(1024)], excl[KHG_NSLOT(1024)], total;
+            KHG_FOR_THREADS(1024)
+            {
+                const uint32_t c = tb + (uint32_t)tid * 8;
+                uint32_t t = 0;
+                if (c >= c_begin && c + 8 <= c_end) {
+                    __builtin_memcpy(v[KHG_SLOT], (const uint32_t*)KHG_ASSUME_ALIGNED(a.chunk_bits + c, 32), 32);
+                } else {
+                    KHG_UNROLL
+                    for (int i = 0; i < 8; ++i) v[KHG_SLOT][i] = (c + i >= c_begin && c + i < c_end) ? a.chunk_bits[c + i] : 0;
+                }
+                KHG_UNROLL
+                for (int i = 0; i < 8; ++i) t += v[KHG_SLOT][i];
+                sum[KHG_SLOT] = t;
             }
-            sh.grp[p][g] = run;
+            KHG_WG_EXCL_SCAN_NW(16, excl, sum, sh.wave[it & 1], total)
+            KHG_FOR_THREADS(1024)
+            {
+                const uint32_t c = tb + (uint32_t)tid * 8;
+                uint64_t o[8];
+                uint64_t at = off + run + excl[KHG_SLOT];
+                KHG_UNROLL
+                for (int i = 0; i < 8; ++i) {
+                    o[i] = at;
+                    at += v[KHG_SLOT][i];
+                }
+                if (c >= c_begin && c + 8 <= c_end) {
+                    __builtin_memcpy((uint64_t*)KHG_ASSUME_ALIGNED(a.chunk_off + c, 64), o, 64);
+                } else {
+                    KHG_UNROLL
+                    for (int i = 0; i < 8; ++i)
+                        if (c + i >= c_begin && c + i < c_end) a.chunk_off[c + i] = o[i];
+                }
+            }
+            run += total;
         }
+        // Compress.h:310-328: pad with '0' to a multiple of 8 bits
+        const uint32_t pad = (uint32_t)((8 - (run & 7)) & 7);
+        const uint64_t padded = run + pad;
+        if (padded >= ((uint64_t)1 << 31)) ok = false;  // HeaderInfo lengths are int (Type.h:5)
+        KHG_FOR_THREADS(1024)
+        {
+            if (tid == 0) {
+                if (padded >= ((uint64_t)1 << 31)) khg_set_status(&a.res->status, -4);
+                a.res->bits[p] = (int32_t)padded;
+                a.res->pads[p] = (int32_t)pad;
+                a.res->k[p] = a.tab_k[p];
+            }
+        }
+        off += padded;
     }
     KHG_BARRIER();
     KHG_FOR_THREADS(1024)
     {
         if (tid == 0) {
             KhgResult* res = a.res;
-            uint64_t off = 36 * 8;
-            int ok = res->status == 0;
-            for (int p = 0; p < 3; ++p) {
-                uint64_t run = 0;  // ... then over the 32 group totals
-                for (int g = 0; g < 32; ++g) {
-                    uint64_t v = sh.grp[p][g];
-                    sh.grp[p][g] = run;
-                    run += v;
-                }
-                // Compress.h:310-328: pad with '0' to a multiple of 8 bits
-                uint32_t pad = (uint32_t)((8 - (run & 7)) & 7);
-                uint64_t padded = run + pad;
-                if (padded >= ((uint64_t)1 << 31)) {  // HeaderInfo lengths are int (Type.h:5)
-                    khg_set_status(&res->status, -4);
-                    ok = 0;
-                }
-                sh.base[p] = off;
-                off += padded;
-                res->bits[p] = (int32_t)padded;
-                res->pads[p] = (int32_t)pad;
-                res->k[p] = a.tab_k[p];
-            }
-            uint64_t table_off = off >> 3;
-            uint64_t total = table_off + 8ull * ((uint64_t)a.tab_k[0] + a.tab_k[1] + a.tab_k[2]);
+            if (res->status != 0) ok = false;
+            const uint64_t table_off = off >> 3;
+            const uint64_t total = table_off + 8ull * ((uint64_t)a.tab_k[0] + a.tab_k[1] + a.tab_k[2]);
             res->total_len = total;
             if (((total + 3) & ~3ull) > a.cap) {
                 khg_set_status(&res->status, -2);
-                ok = 0;
+                ok = false;
             }
             sh.table_off = table_off;
             sh.ok = ok;
@@ -549,40 +560,6 @@ KHG_DEV void khg_scan_body(const KhgEncArgs& a, KhgScanSmem& sh)
                 o[33] = (uint8_t)res->pads[1];
                 o[34] = (uint8_t)res->pads[2];
                 o[35] = (uint8_t)a.lvl;
-            }
-        }
-    }
-    KHG_BARRIER();
-    KHG_FOR_THREADS(1024)
-    {
-        if (sh.ok) {
-            uint32_t* out32 = (uint32_t*)a.out;
-            uint32_t c0 = (uint32_t)tid * per, c1 = c0 + per < a.nchunks ? c0 + per : a.nchunks;
-            uint64_t run[3] = {sh.grp[0][tid >> 5] + sh.psum[0][tid], sh.grp[1][tid >> 5] + sh.psum[1][tid],
-                               sh.grp[2][tid >> 5] + sh.psum[2][tid]};
-            for (uint32_t cb = c0; cb < c1; cb += 8) {
-                uint32_t v[8];
-                KHG_UNROLL
-                for (int i = 0; i < 8; ++i) v[i] = cb + i < c1 ? a.chunk_bits[cb + i] : 0;
-                KHG_UNROLL
-                for (int i = 0; i < 8; ++i) {
-                    const uint32_t c = cb + i;
-                    if (c >= c1) break;
-                    int p = khg_chunk_plane(a, c);
-                    uint64_t off = sh.base[p] + run[p];
-                    uint32_t bits = v[i];
-                    a.chunk_off[c] = off;
-                    run[p] += bits;
-                    if (bits) {  // words shared with neighbouring chunks are OR-merged by the packer: clear them
-                        out32[off >> 5] = 0;
-                        out32[(off + bits - 1) >> 5] = 0;
-                    }
-                }
-            }
-            // the word holding the end of the streams also receives pad bits / the first table bytes
-            if (tid == 0) {
-                uint64_t endbit = sh.table_off * 8;
-                if (endbit > 36 * 8) out32[(endbit - 1) >> 5] = 0;
             }
         }
     }
