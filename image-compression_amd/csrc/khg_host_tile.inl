@@ -84,7 +84,7 @@ extern "C" int khg_tile_lens_dev(khg_ctx* c, void* stream)
     hipLaunchKernelGGL(khg_table_kernel, dim3(3), dim3(256), 0, st, t);
     KhgEncArgs e = khg_enc_args(c->ws, c->tile_rows, c->tile_cols, c->tile_lvl, nullptr, 0, c->tile);
     KHG_HIP(hipMemsetAsync(c->ws.chunk_bits, 0, (size_t)e.nchunks * 4, st));
-    hipLaunchKernelGGL(khg_lens_kernel, dim3(e.nchunks), dim3(256), 0, st, e);
+    hipLaunchKernelGGL(khg_lens_kernel, dim3(e.nchunks < (uint32_t)KHG_TILE_GRID ? e.nchunks : (uint32_t)KHG_TILE_GRID), dim3(256), 0, st, e);
     KHG_HIP(hipGetLastError());
     return khg_end(c, st, 0);
 }
@@ -134,7 +134,7 @@ extern "C" int khg_tile_pack_dev(khg_ctx* c, uint8_t* d_out, size_t cap, void* s
     KhgEncArgs e = khg_enc_args(c->ws, c->tile_rows, c->tile_cols, c->tile_lvl, d_out, cap, c->tile);
     KHG_HIP(hipMemsetAsync(d_out, 0, cap & ~(size_t)3, st));
     hipLaunchKernelGGL(khg_scan_kernel, dim3(1), dim3(1024), 0, st, e);
-    hipLaunchKernelGGL(khg_pack_kernel, dim3(e.nchunks), dim3(256), 0, st, e);
+    hipLaunchKernelGGL(khg_pack_kernel, dim3(e.nchunks < (uint32_t)KHG_TILE_GRID ? e.nchunks : (uint32_t)KHG_TILE_GRID), dim3(256), 0, st, e);
     KHG_HIP(hipGetLastError());
     KHG_HIP(hipMemcpyAsync(c->h_res, c->ws.res, sizeof(KhgResult), hipMemcpyDeviceToHost, st));
     return khg_end(c, st, 1);

@@ -84,10 +84,33 @@ __global__ __launch_bounds__(1024) void khg_meta_kernel(KhgEncArgs a)
     khg_meta_body(a, sh);
 }
 
+// Row-tiled images: a rank owns one chunk in `nranks`, and a workgroup that is started for a chunk only to find it
+// another rank's spends its four waves on the ownership arithmetic.  So the workgroups of these two launches
+// (KHG_TILE_GRID at most) first pick out their chunks -- thread t looks at chunk (j * 256 + t) * gridDim.x +
+// blockIdx.x, which spreads every rank's chunks evenly over the workgroups -- and then work through that list.
+enum { KHG_TILE_GRID = 1024 };
+template <class BODY>
+__device__ __forceinline__ void khg_for_own_chunks(const KhgEncArgs& a, uint32_t* list, uint32_t* count, BODY body)
+{
+    for (uint32_t first = 0; first * gridDim.x + blockIdx.x < a.nchunks; first += 256) {
+        if (threadIdx.x == 0) *count = 0;
+        __syncthreads();
+        const uint64_t c = (uint64_t)(first + threadIdx.x) * gridDim.x + blockIdx.x;
+        if (c < a.nchunks && khg_chunk_info(a, (uint32_t)c).mine) list[atomicAdd(count, 1u)] = (uint32_t)c;
+        __syncthreads();
+        const uint32_t n = *count;
+        for (uint32_t i = 0; i < n; ++i) {
+            body(list[i]);
+            __syncthreads();
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void khg_lens_kernel(KhgEncArgs a)
 {
     __shared__ KhgLensSmem sh;
-    khg_lens_body(a, blockIdx.x, sh);
+    __shared__ uint32_t list[256], count;
+    khg_for_own_chunks(a, list, &count, [&](uint32_t c) { khg_lens_body(a, c, sh); });
 }
 
 __global__ __launch_bounds__(1024) void khg_scan_kernel(KhgEncArgs a)
@@ -99,7 +122,8 @@ __global__ __launch_bounds__(1024) void khg_scan_kernel(KhgEncArgs a)
 __global__ __launch_bounds__(256) void khg_pack_kernel(KhgEncArgs a)
 {
     __shared__ KhgPackSmem sh;
-    khg_pack_body(a, blockIdx.x, sh);
+    __shared__ uint32_t list[256], count;
+    khg_for_own_chunks(a, list, &count, [&](uint32_t c) { khg_pack_body(a, c, sh); });
 }
 
 // rows x cols pixels of a frame, starting at image row row0.
