@@ -132,9 +132,14 @@ extern "C" int khg_tile_pack_dev(khg_ctx* c, uint8_t* d_out, size_t cap, void* s
     int rc = khg_begin(c, st);
     if (rc) return rc;
     KhgEncArgs e = khg_enc_args(c->ws, c->tile_rows, c->tile_cols, c->tile_lvl, d_out, cap, c->tile);
-    KHG_HIP(hipMemsetAsync(d_out, 0, cap & ~(size_t)3, st));
-    hipLaunchKernelGGL(khg_scan_kernel, dim3(1), dim3(1024), 0, st, e);
+    // offsets and the file's length first, so that only the bytes the file will occupy are zeroed (the capacity is
+    // sized for 15 bits per symbol); the header and the tables follow the streams (rank 0 only)
+    KhgEncArgs scan = e;
+    scan.write_meta = 0;
+    hipLaunchKernelGGL(khg_scan_kernel, dim3(1), dim3(1024), 0, st, scan);
+    hipLaunchKernelGGL(khg_clear_share_kernel, dim3(2048), dim3(256), 0, st, d_out, cap, (const KhgResult*)c->ws.res);
     hipLaunchKernelGGL(khg_pack_kernel, dim3(e.nchunks < (uint32_t)KHG_TILE_GRID ? e.nchunks : (uint32_t)KHG_TILE_GRID), dim3(256), 0, st, e);
+    if (e.write_meta) hipLaunchKernelGGL(khg_meta_kernel, dim3(1), dim3(1024), 0, st, e);
     KHG_HIP(hipGetLastError());
     KHG_HIP(hipMemcpyAsync(c->h_res, c->ws.res, sizeof(KhgResult), hipMemcpyDeviceToHost, st));
     return khg_end(c, st, 1);

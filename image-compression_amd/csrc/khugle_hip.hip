@@ -113,6 +113,23 @@ __global__ __launch_bounds__(256) void khg_lens_kernel(KhgEncArgs a)
     khg_for_own_chunks(a, list, &count, [&](uint32_t c) { khg_lens_body(a, c, sh); });
 }
 
+// Zeroes the part of a rank's share buffer the file will occupy (khg_scan_body has just fixed its length): the
+// packer ORs into words that chunks share, and the ranks' shares are added up as whole words.
+__global__ __launch_bounds__(256) void khg_clear_share_kernel(uint8_t* out, size_t cap, const KhgResult* res)
+{
+    if (!res->ok_to_pack) return;
+    size_t bytes = ((size_t)res->total_len + 15) & ~(size_t)15;
+    if (bytes > (cap & ~(size_t)3)) bytes = cap & ~(size_t)3;
+    const size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x, nthreads = (size_t)gridDim.x * 256;
+    if (((uintptr_t)out & 15) == 0) {
+        uint4* o = (uint4*)out;
+        for (size_t i = tid; i < bytes / 16; i += nthreads) o[i] = make_uint4(0, 0, 0, 0);
+        for (size_t i = (bytes & ~(size_t)15) / 4 + tid; i < bytes / 4; i += nthreads) ((uint32_t*)out)[i] = 0;
+    } else {
+        for (size_t i = tid; i < bytes / 4; i += nthreads) ((uint32_t*)out)[i] = 0;
+    }
+}
+
 __global__ __launch_bounds__(1024) void khg_scan_kernel(KhgEncArgs a)
 {
     __shared__ KhgScanSmem sh;

@@ -225,8 +225,9 @@ int khg_batch_decode(khg_batch *b, int n, const uint8_t *const *comp, const size
  *                             each; 0xFFFFFFFF marks "absent")  ->  khg_tile_hist_set
  *   3. khg_tile_lens_dev      table, tree, codes (Huffman.h:87-139; identical on every rank), bits of own chunks
  *   4. khg_tile_bits_get  ->  all-reduce SUM over khg_tile_chunk_count words  ->  khg_tile_bits_set
- *   5. khg_tile_pack_dev      this rank's share of the .comp bytes at their final positions, zero elsewhere
- *                             (rank 0's share holds the header and tables); khg_encode_result: status, file length
+ *   5. khg_tile_pack_dev      this rank's share of the .comp bytes at their final positions, zero elsewhere up to
+ *                             the file's length (rank 0's share holds the header and tables; bytes behind the
+ *                             file's length are left as they were); khg_encode_result: status, file length
  *   6. reduce SUM (or OR) of the shares as 32-bit words to the rank that keeps the file -- or, moving each byte
  *      once: khg_tile_chunk_off_get gives every chunk's bit offset in the file (the same on all ranks after step
  *      5), a rank's chunks are the ones whose bits were non-zero before step 4's all-reduce, so each rank sends the

@@ -474,13 +474,22 @@ void khgsim_tile_bits_set(void* h, const uint32_t* bits) {
 int khgsim_tile_pack(void* h, uint8_t* out, size_t cap, size_t* total) {
     SimTile* T = (SimTile*)h;
     KhgEncArgs e = khg_enc_args(T->S.ws, T->rows, T->cols, T->lvl, out, cap, T->t);
-    memset(out, 0, cap & ~(size_t)3);
+    // as khg_tile_pack_dev: offsets and length, the file's bytes zeroed (junk behind them), packer, header + tables
+    memset(out, 0xA5, cap);
+    KhgEncArgs scan = e;
+    scan.write_meta = 0;
     KhgScanSmem* ssh = new KhgScanSmem;
-    khg_scan_body(e, *ssh);
-    delete ssh;
+    khg_scan_body(scan, *ssh);
+    if (T->S.ws.res->ok_to_pack) {
+        size_t bytes = ((size_t)T->S.ws.res->total_len + 15) & ~(size_t)15;
+        if (bytes > (cap & ~(size_t)3)) bytes = cap & ~(size_t)3;
+        memset(out, 0, bytes);
+    }
     KhgPackSmem* psh = new KhgPackSmem;
     for (uint32_t c = 0; c < e.nchunks; ++c) khg_pack_body(e, c, *psh);
     delete psh;
+    if (e.write_meta) khg_meta_body(e, *ssh);
+    delete ssh;
     *total = (size_t)T->S.ws.res->total_len;
     return T->S.ws.res->status;
 }
