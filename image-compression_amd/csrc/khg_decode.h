@@ -965,6 +965,186 @@ KHG_DEV void khg_dec_chain_body(const KhgDecArgs& a, int bid, KhgDecChainSmem& s
     }
 }
 
+// ---- The same chain for long streams, in two launches with one workgroup per batch of workgroup maps instead of one
+// workgroup per plane walking through all batches (a 32768 x 32768 image has 69 batches of 256 in its luma stream).
+// First launch: every batch's composed map, entry offset -> (landing offset, codewords), kept in spare words of the
+// batch's own records.  Second launch: every workgroup chains the maps of the batches before its own (staged in LDS,
+// one dependent lookup per batch) and then finishes its batch as khg_dec_chain_body does; the last one also writes
+// the totals and clears the tail.
+#ifndef KHG_CHAIN_GROUPS
+#define KHG_CHAIN_GROUPS 16  // groups of 16 workgroup maps per batch (the simulator's build uses fewer)
+#endif
+enum { KHG_CHAIN_BATCH = 16 * KHG_CHAIN_GROUPS };
+
+// Batch map entry o of the batch whose first record is `first`: two spare words of record o / 3.
+KHG_DEV uint32_t* khg_batch_map_slot(KhgBlkInfo* first, uint32_t o) { return &first[o / 3].pad_[2 * (o % 3)]; }
+
+struct KhgDecChainSplitSmem {
+    uint32_t map[KHG_CHAIN_BATCH * KHG_MAXOFF];
+    uint32_t gmap[KHG_CHAIN_GROUPS * KHG_MAXOFF];
+    uint32_t goff[KHG_CHAIN_GROUPS], gout[KHG_CHAIN_GROUPS];
+    uint32_t off, out;
+    uint32_t total;
+};
+
+// Stages the maps of batch `batch` and composes its groups of 16 for every entry offset (the first two steps of
+// khg_dec_chain_body).  Returns the number of maps staged (0: nothing to do).
+KHG_DEV uint32_t khg_chain_stage_batch(const KhgDecArgs& a, int p, uint32_t batch, uint32_t nb, uint32_t M,
+                                       KhgDecChainSplitSmem& sh)
+{
+    const KhgBlkInfo* blk = a.blk + a.blk0[p];
+    const uint32_t t0 = batch * KHG_CHAIN_BATCH;
+    const uint32_t nt = nb - t0 < (uint32_t)KHG_CHAIN_BATCH ? nb - t0 : (uint32_t)KHG_CHAIN_BATCH;
+    KHG_FOR_THREADS(256)
+    {
+        for (uint32_t i = (uint32_t)tid; i < nt * M; i += 256) {
+            const uint32_t b = i / M, o = i - b * M;
+            sh.map[b * KHG_MAXOFF + o] = blk[t0 + b].map[o];
+        }
+    }
+    KHG_BARRIER();
+    KHG_FOR_THREADS(256)
+    {
+        for (uint32_t idx = (uint32_t)tid; idx < (uint32_t)KHG_CHAIN_GROUPS * M; idx += 256) {
+            const uint32_t g = idx / M, o = idx - g * M;
+            uint32_t off = o, tot = 0;
+            for (uint32_t b = 16 * g; b < 16 * g + 16 && b < nt; ++b) {
+                if (off < M) {
+                    const uint32_t e = sh.map[b * KHG_MAXOFF + off];
+                    tot += e & 0xFFFFFFu;
+                    off = e >> 24;
+                }
+            }
+            sh.gmap[g * KHG_MAXOFF + o] = ((off < M ? off : (uint32_t)KHG_OFF_NONE) << 24) | tot;
+        }
+    }
+    KHG_BARRIER();
+    return nt;
+}
+
+KHG_DEV void khg_dec_chain_maps_body(const KhgDecArgs& a, int p, uint32_t batch, KhgDecChainSplitSmem& sh)
+{
+    if (!a.hdr->ok) return;
+    const uint32_t nb = khg_dec_active_blocks((uint32_t)a.hdr->nbits[p]);
+    const uint32_t M = (uint32_t)a.hdr->maxlen[p] <= (uint32_t)KHG_MAXOFF ? (uint32_t)a.hdr->maxlen[p] : 0u;
+    // the last batch's map is nobody's predecessor
+    if (M == 0 || (uint64_t)(batch + 1) * KHG_CHAIN_BATCH >= nb) return;
+    khg_chain_stage_batch(a, p, batch, nb, M, sh);
+    KHG_FOR_THREADS(256)
+    {
+        if ((uint32_t)tid < M) {
+            uint32_t off = (uint32_t)tid, tot = 0;  // at most 256 x 2^16 codewords: a word of its own
+            for (uint32_t g = 0; g < (uint32_t)KHG_CHAIN_GROUPS; ++g) {
+                if (off < M) {
+                    const uint32_t e = sh.gmap[g * KHG_MAXOFF + off];
+                    tot += e & 0xFFFFFFu;
+                    off = e >> 24;
+                }
+            }
+            uint32_t* slot = khg_batch_map_slot(a.blk + a.blk0[p] + batch * KHG_CHAIN_BATCH, (uint32_t)tid);
+            slot[0] = off < M ? off : (uint32_t)KHG_OFF_NONE;
+            slot[1] = tot;
+        }
+    }
+}
+
+KHG_DEV void khg_dec_chain_finish_body(const KhgDecArgs& a, int p, uint32_t batch, KhgDecChainSplitSmem& sh)
+{
+    if (!a.hdr->ok) return;
+    const uint32_t nb = khg_dec_active_blocks((uint32_t)a.hdr->nbits[p]);
+    const uint32_t M = (uint32_t)a.hdr->maxlen[p] <= (uint32_t)KHG_MAXOFF ? (uint32_t)a.hdr->maxlen[p] : 0u;
+    const uint32_t nbatch = (nb + KHG_CHAIN_BATCH - 1) / KHG_CHAIN_BATCH;
+    const bool tail = batch + 1 == nbatch || (nbatch == 0 && batch == 0);  // this workgroup closes the plane
+    if (batch >= nbatch && !tail) return;
+    if ((uint64_t)2 * batch * M > (uint64_t)KHG_CHAIN_BATCH * KHG_MAXOFF) {  // more batches than the staging area holds
+        KHG_FOR_THREADS(256) { if (tid == 0) khg_set_status(&a.res->status, -6); }
+        return;
+    }
+    KhgBlkInfo* blk = a.blk + a.blk0[p];
+    // the maps of the batches before this one, two words per entry offset, in the (still free) map area
+    KHG_FOR_THREADS(256)
+    {
+        for (uint32_t i = (uint32_t)tid; i < batch * M; i += 256) {
+            const uint32_t k = i / M, o = i - k * M;
+            const uint32_t* slot = khg_batch_map_slot(blk + k * KHG_CHAIN_BATCH, o);
+            sh.map[2 * i] = slot[0];
+            sh.map[2 * i + 1] = slot[1];
+        }
+    }
+    KHG_BARRIER();
+    KHG_FOR_THREADS(256)
+    {
+        if (tid == 0) {
+            uint32_t off = M ? 0 : (uint32_t)KHG_OFF_NONE, out = 0;
+            for (uint32_t k = 0; k < batch; ++k) {
+                if (off < M) {
+                    const uint32_t tot = sh.map[2 * (k * M + off) + 1];
+                    out = out + tot < out ? 0xFFFFFFFFu : out + tot;
+                    off = sh.map[2 * (k * M + off)];
+                }
+            }
+            sh.off = off;
+            sh.out = out;
+        }
+    }
+    KHG_BARRIER();
+    const uint32_t nt = nbatch ? khg_chain_stage_batch(a, p, batch, nb, M, sh) : 0;
+    const uint32_t t0 = batch * KHG_CHAIN_BATCH;
+    KHG_FOR_THREADS(256)
+    {
+        if (tid == 0) {
+            uint32_t off = sh.off, out = sh.out;
+            for (uint32_t g = 0; g < (uint32_t)KHG_CHAIN_GROUPS; ++g) {
+                sh.goff[g] = off;
+                sh.gout[g] = out;
+                if (off < M && 16 * g < nt) {
+                    const uint32_t e = sh.gmap[g * KHG_MAXOFF + off];
+                    const uint32_t tot = e & 0xFFFFFFu;
+                    out = out + tot < out ? 0xFFFFFFFFu : out + tot;
+                    off = e >> 24;
+                }
+            }
+            sh.off = off;
+            sh.out = out;
+        }
+    }
+    KHG_BARRIER();
+    KHG_FOR_THREADS(256)
+    {
+        if (tid < KHG_CHAIN_GROUPS) {
+            uint32_t off = sh.goff[tid], out = sh.gout[tid];
+            for (uint32_t b = 16 * (uint32_t)tid; b < 16 * (uint32_t)tid + 16 && b < nt; ++b) {
+                blk[t0 + b].start_off = off;
+                blk[t0 + b].out = out;
+                if (off < M) {
+                    const uint32_t e = sh.map[b * KHG_MAXOFF + off];
+                    const uint32_t tot = e & 0xFFFFFFu;
+                    out = out + tot < out ? 0xFFFFFFFFu : out + tot;
+                    off = e >> 24 < M ? e >> 24 : (uint32_t)KHG_OFF_NONE;
+                }
+            }
+        }
+    }
+    if (!tail) return;
+    KHG_FOR_THREADS(256)
+    {
+        if (tid == 0) {
+            uint32_t out = sh.out;
+            if (out > a.n[p]) {
+                khg_set_status(&a.res->status, -3);  // the reference would write out of bounds
+                out = a.n[p];
+            }
+            a.res->bits[p] = (int32_t)out;  // symbols decoded
+            sh.total = out;
+        }
+    }
+    KHG_BARRIER();
+    KHG_FOR_THREADS(256)
+    {
+        for (uint32_t i = sh.total + (uint32_t)tid; i < a.n[p]; i += 256) a.sym[p][i] = 0;
+    }
+}
+
 struct KhgDecWriteSmem {
     uint32_t lut[KHG_LUT_SIZE];
     uint32_t stage[KHG_STAGE_LDS];

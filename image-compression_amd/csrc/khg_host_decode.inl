@@ -78,7 +78,7 @@ static int khg_decode_enqueue(khg_ctx* c, const uint8_t* d_comp, size_t len, int
     } else {
         hipLaunchKernelGGL((khg_dec_map_kernel<KHG_MAP_SMALL>), dim3(grid_dec), dim3(256), 0, st, d);
         hipLaunchKernelGGL((khg_dec_map_kernel<KHG_MAXOFF>), dim3(grid_dec), dim3(256), 0, st, d);
-        hipLaunchKernelGGL(khg_dec_chain_kernel, dim3(3), dim3(256), 0, st, d);
+        khg_launch_chain(st, d);
     }
     hipLaunchKernelGGL(khg_dec_write_kernel, dim3(grid_dec), dim3(256), 0, st, d);
     if (coeff_picture) {  // Decompress.h:234-262: the dequantised coefficients through the colour conversion, no IWT2D

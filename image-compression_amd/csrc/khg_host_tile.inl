@@ -264,7 +264,7 @@ extern "C" int khg_tile_decode_write_dev(khg_ctx* c, uint32_t* bounds, void* str
     if (rc) return rc;
     const KhgDecArgs d = khg_tdec_args(c);
     const int n = c->tile.nranks;
-    hipLaunchKernelGGL(khg_dec_chain_kernel, dim3(3), dim3(256), 0, st, d);
+    khg_launch_chain(st, d);
     const unsigned grid = khg_tdec_grid(c);
     if (grid) hipLaunchKernelGGL(khg_dec_write_kernel, dim3(grid), dim3(256), 0, st, d);
     KHG_HIP(hipGetLastError());

@@ -181,6 +181,40 @@ __global__ __launch_bounds__(256) void khg_dec_chain_kernel(KhgDecArgs a)
     khg_dec_chain_body(a, (int)blockIdx.x, sh);
 }
 
+// The chain of a long stream: blockIdx.x = batch of KHG_CHAIN_BATCH workgroup maps, blockIdx.y = colour component.
+__global__ __launch_bounds__(256) void khg_dec_chain_maps_kernel(KhgDecArgs a)
+{
+    __shared__ KhgDecChainSplitSmem sh;
+    khg_dec_chain_maps_body(a, (int)blockIdx.y, blockIdx.x, sh);
+}
+__global__ __launch_bounds__(256) void khg_dec_chain_finish_kernel(KhgDecArgs a)
+{
+    __shared__ KhgDecChainSplitSmem sh;
+    khg_dec_chain_finish_body(a, (int)blockIdx.y, blockIdx.x, sh);
+}
+
+// Files that can hold more than KHG_CHAIN_SPLIT_FROM batches (by the bound their length gives) take the two launches
+// with a workgroup per batch (an 8K frame, five batches: 8 + 10 us against 30 us); smaller ones the single launch.
+#ifndef KHG_CHAIN_SPLIT_FROM
+#define KHG_CHAIN_SPLIT_FROM 1
+#endif
+static void khg_launch_chain(hipStream_t st, const KhgDecArgs& d)
+{
+    const uint64_t nb = (8 * d.len + KHG_BLK_BITS - 1) / KHG_BLK_BITS + 1;
+    const unsigned nbatch = (unsigned)((nb + KHG_CHAIN_BATCH - 1) / KHG_CHAIN_BATCH);
+#ifdef KHG_TIMING  // the developer build keeps clock stamps in the records' spare words
+    const bool split = false;
+#else
+    const bool split = nbatch > KHG_CHAIN_SPLIT_FROM;
+#endif
+    if (split) {
+        hipLaunchKernelGGL(khg_dec_chain_maps_kernel, dim3(nbatch, 3), dim3(256), 0, st, d);
+        hipLaunchKernelGGL(khg_dec_chain_finish_kernel, dim3(nbatch, 3), dim3(256), 0, st, d);
+    } else {
+        hipLaunchKernelGGL(khg_dec_chain_kernel, dim3(3), dim3(256), 0, st, d);
+    }
+}
+
 __global__ __launch_bounds__(256) void khg_dec_write_kernel(KhgDecArgs a)
 {
     __shared__ KhgDecWriteSmem sh;

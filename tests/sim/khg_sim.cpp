@@ -175,6 +175,23 @@ int khgsim_encode(const uint8_t* r, const uint8_t* g, const uint8_t* b, int rows
     return sim_encode(S, r, g, b, rows, cols, lvl, out, cap, out_len);
 }
 
+// The chain over the workgroup maps: in one piece (short streams on the GPU) or, when KHGSIM_CHAIN_SPLIT is set in
+// the environment, as the two launches long streams take (batches of 16 * KHG_CHAIN_GROUPS maps).
+static void sim_chain(const KhgDecArgs& d, KhgDecChainSmem& one) {
+    const char* env = getenv("KHGSIM_CHAIN_SPLIT");
+    if (!env || !*env || *env == '0') {
+        for (int p = 0; p < 3; ++p) khg_dec_chain_body(d, p, one);
+        return;
+    }
+    KhgDecChainSplitSmem* sh = new KhgDecChainSplitSmem;
+    const uint32_t nbatch = (uint32_t)(((8 * d.len + KHG_BLK_BITS - 1) / KHG_BLK_BITS + 1 + KHG_CHAIN_BATCH - 1) / KHG_CHAIN_BATCH);
+    for (int p = 0; p < 3; ++p)
+        for (uint32_t b = 0; b < nbatch; ++b) khg_dec_chain_maps_body(d, p, b, *sh);
+    for (int p = 0; p < 3; ++p)
+        for (uint32_t b = nbatch; b-- > 0;) khg_dec_chain_finish_body(d, p, b, *sh);  // any order
+    delete sh;
+}
+
 // Mirrors khg_decode_dev / khg_tile_decode_dev (r, g, b receive the tile's rows only) / khg_decode_ycbcr_dev.
 static void sim_inverse(SimWs& S, int rows, int cols, uint8_t* r, uint8_t* g, uint8_t* b, KhgTile tile,
                         double* const ycbcr[3], size_t bgr_stride = 0) {
@@ -219,7 +236,7 @@ static int sim_decode(SimWs& S, const uint8_t* comp, size_t len, int rows, int c
     } else {
         for (uint32_t b_ = 0; b_ < d.nblocks; ++b_) khg_dec_map_body<KHG_MAP_SMALL>(d, b_, *lsh);
         for (uint32_t b_ = 0; b_ < d.nblocks; ++b_) khg_dec_map_body<KHG_MAXOFF>(d, b_, *lsh2);
-        for (int p = 0; p < 3; ++p) khg_dec_chain_body(d, p, *ssh);
+        sim_chain(d, *ssh);
     }
     if (passes_used) *passes_used = 1;
     for (uint32_t b_ = 0; b_ < d.nblocks; ++b_) khg_dec_write_body(d, b_, *wsh);
@@ -564,7 +581,7 @@ int khgsim_tile_decode_write(void* h, uint32_t* bounds) {
     KhgDecArgs d = T->dec_args();
     const int n = T->t.nranks;
     KhgDecChainSmem* ssh = new KhgDecChainSmem;
-    for (int p = 0; p < 3; ++p) khg_dec_chain_body(d, p, *ssh);
+    sim_chain(d, *ssh);
     delete ssh;
     KhgDecWriteSmem* wsh = new KhgDecWriteSmem;
     const uint32_t grid = T->grid();

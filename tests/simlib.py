@@ -20,8 +20,10 @@ def build(force=False):
     if force or not os.path.exists(SO) or os.path.getmtime(SO) < max(os.path.getmtime(d) for d in deps):
         # KHG_PS_BATCH_BITS: the single-pass packer's LDS batches hold 20000 bits here instead of 114688, so that the
         # entries of ordinary pictures are assembled in one batch (detail rows) and in several (rows with LL symbols)
+        # KHG_CHAIN_GROUPS: the long-stream form of the decoder's chain (KHGSIM_CHAIN_SPLIT=1) takes batches of 32
+        # workgroup maps instead of 256, so that pictures of a megapixel already span several
         subprocess.check_call(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-I" + CSRC,
-                               "-DKHG_PS_BATCH_BITS=20000", "-o", SO, SRC])
+                               "-DKHG_PS_BATCH_BITS=20000", "-DKHG_CHAIN_GROUPS=2", "-o", SO, SRC])
 
 
 def lib():

@@ -160,6 +160,26 @@ def test_decode(shape):
     assert np.array_equal(out, O.decode(comp))
 
 
+def test_decode_with_the_chain_of_long_streams(monkeypatch):
+    """The decoder's chain as long streams take it: one workgroup per batch of workgroup maps, two launches.  A
+    1024 x 1536 frame has 54 workgroups in its luma stream, two batches of 32 in the simulator's build; noise at the
+    Normal preset 150, five batches; small pictures a single, partly filled batch; a flat one an empty stream."""
+    import craft
+    monkeypatch.setenv("KHGSIM_CHAIN_SPLIT", "1")
+    rng = np.random.default_rng(3)
+    cases = [(synth_frame(1024, 1536, 9, 0), 1), (rng.integers(0, 256, (3, 1024, 1536), dtype=np.uint8), 0),
+             (synth_frame(64, 96, 2, 1), 2)]
+    cases += [(rgb, 0) for rgb in craft.stress_images(72, 136).values()]
+    for rgb, lvl in cases:
+        comp = O.encode(rgb, lvl)
+        rc, out, q, _ = S.decode(comp, rgb.shape[1], rgb.shape[2])
+        assert rc == 0
+        (wq, _) = O.decode_planes(comp)
+        for g, w in zip(q, wq):
+            assert np.array_equal(g.astype(np.int32), w)
+        assert np.array_equal(out, O.decode(comp))
+
+
 def test_decode_reference_files():
     for ref in ("cat_high", "couple_normal", "library_extreme"):
         comp = open(os.path.join(RUN, ref + ".comp"), "rb").read()

@@ -6,7 +6,7 @@
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 SO=/tmp/libkhg_sim_asan.so
-g++ -std=c++17 -O1 -g -fsanitize=address -fno-omit-frame-pointer -ffp-contract=off -fPIC -shared -DKHG_SIM_SLACK=0 -DKHG_PS_BATCH_BITS=20000 \
+g++ -std=c++17 -O1 -g -fsanitize=address -fno-omit-frame-pointer -ffp-contract=off -fPIC -shared -DKHG_SIM_SLACK=0 -DKHG_PS_BATCH_BITS=20000 -DKHG_CHAIN_GROUPS=2 \
     -I"$ROOT/image-compression_amd/csrc" -o $SO "$ROOT/tests/sim/khg_sim.cpp"
 cat > /tmp/run_asan_suite.py <<PY
 import sys
