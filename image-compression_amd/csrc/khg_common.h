@@ -291,6 +291,19 @@ KHG_DEV double khg_div_const(double x, double c, double rc)
     return khg_fma(r, rc, q);
 }
 
+// Workgroups are dealt out to the chip's 8 XCDs (each with its own L2) round robin by their id.  This maps a
+// launch's workgroup id to a work index such that runs of 8 consecutive pieces of work go to one XCD: neighbouring
+// pieces -- which share cache lines at their edges and read each other's halo -- then meet in one L2 instead of
+// two (a line written in part from two XCDs goes to memory as two masked writes).  It transposes every aligned
+// block of 64 ids as an 8 x 8 matrix and leaves a last partial block alone, so the order in which kinds of work
+// reach the CUs stays what the launch plan laid out.  A bijection on [0, n) for any n; where the hardware deals
+// differently the result is as correct, only slower.
+KHG_DEV int khg_xcd_remap(int wg, int n)
+{
+    if ((wg | 63) >= n) return wg;
+    return (wg & ~63) | ((wg & 7) << 3) | ((wg >> 3) & 7);
+}
+
 // Rows [*r0, *r1) of segment `seg` of `nseg` over the even row range [begin, end): the row pairs are dealt out evenly,
 // segments differ by at most one pair.
 KHG_DEV void khg_segment_rows(int begin, int end, int nseg, int seg, int* r0, int* r1)

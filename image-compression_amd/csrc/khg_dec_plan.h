@@ -137,6 +137,7 @@ static inline KhgInvArgs khg_inv_args(const KhgWorkspace& ws, const KhgDecWorksp
     for (int i = 0; i < n; ++i) {
         khg_inv_plane(&a.pl[i], ws, dws, rows, cols, comp0 + i, level, tile, dst ? dst[comp0 + i] : nullptr);
         g[i].pw = a.pl[i].pw; g[i].span = a.pl[i].row_end - a.pl[i].row_begin; g[i].weight = 1;
+        g[i].strip_pairs = KHG_STRIP_PAIRS;
     }
     a.nwg = khg_plan_groups(g, n, KHG_INV_SLOTS);
     for (int i = 0; i < n; ++i) {

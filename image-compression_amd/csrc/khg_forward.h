@@ -1,20 +1,22 @@
 // khg_forward.h -- colour transform + one 2-D CDF 9/7 lifting level + quantiser + histogram.
 //
-// Lane-streaming layout.  A wave owns a strip of 64 sample pairs (128 columns) of the plane being transformed and
-// walks down a segment of its rows, two rows per trip; lane l holds the pair (x[2p], x[2p+1]), p = first pair + l:
+// Lane-streaming layout.  A wave owns a strip of 64 * LP sample pairs of the plane being transformed and walks down a
+// segment of its rows, two rows per trip; lane l holds LP neighbouring pairs (x[2p], x[2p+1]), p = first pair + LP l + a:
 //   rows   : the four lifting steps of a row need the neighbouring pair's value once each (e[p+1], d1[p-1],
-//            s1[p+1], d2[p-1]); those come from the neighbouring LANE by a DPP wave shift, so a row is transformed
-//            where it was loaded, with no window recomputed per thread, no staging tile and no barrier.  The two
-//            pairs at each end of a strip are halo (their results are wrong and not used): 60 of 64 pairs are output.
+//            s1[p+1], d2[p-1]); inside a lane that is another register, at the lane's ends it comes from the
+//            neighbouring LANE by a DPP wave shift, so a row is transformed where it was loaded, with no window
+//            recomputed per thread, no staging tile and no barrier.  The two pairs at each end of a strip are halo
+//            (their results are wrong and not used): 60 of 64 pairs are output with one pair per lane, 124 of 128
+//            with two (and half the lane exchanges per sample).
 //            Halo pairs that fall outside the plane are LOADED mirrored (whole-sample symmetric extension about the
 //            first and the last sample: x[-i] = x[i], x[n-1+i] = x[n-1-i]).  Lifting preserves that symmetry and
 //            a + b == b + a bit for bit, so the interior formula then yields exactly what the reference's edge
 //            lines compute (DWT.h:18,26,34,42: x[n-1] += 2*a*x[n-2], x[0] += 2*a*x[1], and 2*a*x == a*(x+x)), and
 //            the row pass has no edge case at all.  A mirrored pair is the memory pair (x[i], x[i+1]) read backwards,
-//            so a lane carries its load column and which of the two samples is its even one.
-//   columns: the lane's two packed output columns (low half p, high half w/2 + p) each run the streaming lifting
+//            so a lane carries its load column and where in the loaded window each of its samples sits.
+//   columns: each pair's two packed output columns (low half p, high half w/2 + p) run the streaming lifting
 //            pipeline of khg_fwd_step over the rows as they arrive, state in registers.  Finished coefficients are
-//            scaled and emitted at once: level-1 LL to an f64 buffer (input of level 2), everything else quantised
+//            emitted at once: level-1 LL scaled to an f64 buffer (input of level 2), everything else quantised
 //            to int16 symbols in Mallat layout and counted (count + first raster index).
 // Sources: u8 RGB -> Y (Main.cpp:200-202, Colorspace.h:11), u8 RGB -> Cb and Cr together (one load of the pixel feeds
 // both planes; Colorspace.h:15-22 decimation: the pixel at even row, even column), or an f64 plane.
@@ -30,13 +32,17 @@ enum { KHG_SRC_Y = 0, KHG_SRC_C = 1, KHG_SRC_PLANE = 3, KHG_SRC_Y_BGR = 4, KHG_S
 
 enum {
     KHG_LANES = 64,
-    KHG_STRIP_PAIRS = 60,        // output pairs per wave strip (64 lanes minus two halo pairs per side)
+    KHG_STRIP_PAIRS = 60,        // output pairs per wave strip at one pair per lane (64 lanes minus two halo pairs per side)
     KHG_WG_STRIPS = 4,           // waves (adjacent strips) per workgroup
     KHG_MAX_SEG_ROWS = 120,      // rows per workgroup segment, at most
     KHG_RD_PAD = 4,              // the column pipeline also looks up the row pairs it only flushes
-    KHG_RD_N = KHG_WG_STRIPS * KHG_STRIP_PAIRS + 4 + KHG_MAX_SEG_ROWS / 2 + 2 * KHG_RD_PAD  // reciprocals per band
+    KHG_TALLY_TRIPS = 16,        // a lane's 8-bit symbol tallies go to the workgroup histogram every so many trips
+    KHG_DUMP_BYTES = 8192        // room behind a symbol plane and an LL buffer for the stores that have no output
 };
-static_assert(4 * (KHG_MAX_SEG_ROWS / 2) <= 255, "a lane's symbol tallies (KhgHot) are 8-bit fields");
+// output pairs per wave strip with LP pairs per lane, and reciprocals per band that a workgroup tabulates
+#define KHG_STRIP_PAIRS_LP(LP) (64 * (LP) - 4)
+#define KHG_RD_N_LP(LP) (KHG_WG_STRIPS * KHG_STRIP_PAIRS_LP(LP) + 4 + KHG_MAX_SEG_ROWS / 2 + 2 * KHG_RD_PAD)
+static_assert(3 * 2 * KHG_TALLY_TRIPS <= 255, "a lane's symbol tallies are 8-bit fields");
 
 // One plane of a launch.
 struct KhgFwdPlane {
@@ -47,6 +53,8 @@ struct KhgFwdPlane {
     int ll_pitch;
     int16_t* sym;              // symbol plane of this colour component
     int sym_pitch;
+    uint32_t sym_dump, ll_dump;  // byte offsets behind the symbol plane / the LL buffer of KHG_DUMP_BYTES that take the
+                                 // stores of lanes and trips without output (see khg_fwd_wg_body)
     double* coef;              // optional f64 tap of every coefficient (may be null)
     int coef_pitch;
     uint32_t* hist_cnt;        // [KHG_NBINS]
@@ -72,28 +80,52 @@ struct KhgFwdArgs {
     int lvl;                   // preset 0..2
     int nplanes;
     int nwg;                   // workgroups of the launch
+    int lp;                    // sample pairs per lane (1 or 2) of the luma / plane workgroups: which instantiation
+                               // of the kernel the grid is planned for
+    int lpc;                   // the same for the workgroups that carry Cb and Cr (RGB launches)
     // RGB launch: [0] = Y, [1] = Cb, [2] = Cr (Cb and Cr share one grid: a lane carries both).
     // Plane launches: up to three independent planes.
     KhgFwdPlane pl[3];
     int lhist;                 // level 2: bins of the workgroup histogram in use (a power of two up to the capacity)
 };
 
+// Two pairs per lane need every plane of the launch to hold an even number of pairs (a lane's two pairs are then
+// inside or outside the plane together, and their symbols and LL values are stored as one aligned word).
+// Pairs per lane of the workgroups that carry Cb and Cr together.  With two they hold twice the column state of a
+// luma workgroup (194 registers: two workgroups per CU instead of four), and the launch then took as long as with one
+// pair per lane everywhere; with one, luma's two pairs fit the 128 registers of four workgroups per CU.
+#ifndef KHG_FWD_LPC
+#define KHG_FWD_LPC 1
+#endif
+static inline int khg_fwd_lp_for(const KhgFwdArgs& a)
+{
+#ifdef KHG_FWD_FORCE_LP1  // developer builds: the one-pair kernels everywhere
+    return 1;
+#endif
+    for (int p = 0; p < a.nplanes; ++p)
+        if ((a.pl[p].pw / 2) % 2) return 1;
+    return 2;
+}
+
 // LDS of one workgroup.  Level 1 emits detail bands only (small symbols, three bands): 256 bins.  Level 2 also emits
 // the LL band, whose symbols spread over hundreds of values and at the Normal preset (LL step 1.011) reach 1009: room
-// for 2048 bins (more would cost the fourth workgroup per CU that the launch plan counts on), of which a launch uses
+// for 2048 bins (more would cost a resident workgroup per CU that the launch plan counts on), of which a launch uses
 // KhgFwdArgs::lhist.  Symbols outside the bins go to the global histogram one atomic at a time, and neighbouring LL
 // symbols collide there: with 1024 bins the Normal preset's level 2 took 0.75 ms instead of 0.05.
-template <int LEVEL, int NP>
+template <int LEVEL, int NP, int LP>
 struct KhgFwdSmem {
-    enum { LHIST = LEVEL == 1 ? 256 : 2048, LHIST_BIAS = LHIST / 2, NBAND = LEVEL == 1 ? 3 : 4 };
+    enum { LHIST = LEVEL == 1 ? 256 : 2048, LHIST_BIAS = LHIST / 2, NBAND = LEVEL == 1 ? 3 : 4, RD_N = KHG_RD_N_LP(LP) };
     uint32_t cnt[NP][LHIST];    // symbols [-LHIST/2, LHIST/2)
     uint32_t first[NP][LHIST];
-    double rdiv[NBAND * KHG_RD_N];  // 1/divisor of band slot s at diagonal u: [s * KHG_RD_N + KHG_RD_PAD + u]
+    double rdiv[NBAND * RD_N];  // band slot s at diagonal u: [s * RD_N + KHG_RD_PAD + u] (see khg_fwd_rdiv_entry)
 };
 union KhgFwdSmemAny {
-    KhgFwdSmem<1, 1> y;
-    KhgFwdSmem<1, 2> c;
-    KhgFwdSmem<2, 1> l2;
+    KhgFwdSmem<1, 1, 1> y1;
+    KhgFwdSmem<1, 2, 1> c1;
+    KhgFwdSmem<2, 1, 1> l21;
+    KhgFwdSmem<1, 1, 2> y2;
+    KhgFwdSmem<1, 2, 2> c2;
+    KhgFwdSmem<2, 1, 2> l22;
 };
 
 // Streaming state of one 1-D lifting line: values of pair j-1 (e, o, d1, s1) and d2 of pair j-2.
@@ -128,12 +160,13 @@ KHG_DEV void khg_fwd_step(KhgLift& st, double en, double on, double& s2, double&
 }
 
 // DWT.h:45-50: a = 1/1.149604398 (rounded once); odd samples x*a, even samples x/a.
+#define KHG_SCALE_A (1 / 1.149604398)
 KHG_DEV double khg_fwd_scale_even(double x)
 {
-    const double a = 1 / 1.149604398, ra = 1 / a;
+    const double a = KHG_SCALE_A, ra = 1 / a;
     return khg_div_const(x, a, ra);
 }
-KHG_DEV double khg_fwd_scale_odd(double x) { const double a = 1 / 1.149604398; return x * a; }
+KHG_DEV double khg_fwd_scale_odd(double x) { const double a = KHG_SCALE_A; return x * a; }
 
 // ---- neighbour lanes.  khg_lane_next(v): the value lane l+1 holds, khg_lane_prev(v): lane l-1's.  What the lane
 // at the end of a wave receives is unspecified (whatever its destination register held): that lane is halo.
@@ -157,6 +190,9 @@ __device__ __forceinline__ double khg_lane_prev(double v)
 // and conditions on it become scalar branches).
 #define KHG_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
 KHG_DEV int khg_f2i(double n) { return (int)n; }  // v_cvt_i32_f64 saturates
+KHG_DEV uint32_t khg_hi32(double v) { return (uint32_t)__double2hiint(v); }
+// the low halves of a and b in one word (a in bits 0-15)
+KHG_DEV uint32_t khg_pack16(int a, int b) { return __builtin_amdgcn_perm((uint32_t)b, (uint32_t)a, 0x05040100u); }
 #else
 #define KHG_LANE_NEXT(dst, src) \
     for (int t_ = 0; t_ < 256; ++t_) (dst)[t_] = (t_ & 63) == 63 ? (src)[t_] : (src)[t_ + 1];
@@ -164,6 +200,8 @@ KHG_DEV int khg_f2i(double n) { return (int)n; }  // v_cvt_i32_f64 saturates
     for (int t_ = 0; t_ < 256; ++t_) (dst)[t_] = (t_ & 63) == 0 ? (src)[t_] : (src)[t_ - 1];
 #define KHG_UNIFORM(x) (x)
 static inline int khg_f2i(double n) { return n >= 2147483647.0 ? 2147483647 : (n <= -2147483648.0 ? (-2147483647 - 1) : (int)n); }
+static inline uint32_t khg_hi32(double v) { uint64_t u; memcpy(&u, &v, 8); return (uint32_t)(u >> 32); }
+static inline uint32_t khg_pack16(int a, int b) { return ((uint32_t)a & 0xFFFFu) | ((uint32_t)b << 16); }
 #endif
 
 // Image row `row` as a row of the r/g/b buffers.  Rows a segment reads beyond those its outputs need may, for a band
@@ -176,12 +214,13 @@ KHG_DEV int khg_band_row(const KhgFwdArgs& a, int row)
 
 // ---- source of one lane for one row pair, as loaded (converted when the rows are transformed, one trip later,
 // so the loads fly during the previous trip's arithmetic).
-template <int SRC>
+template <int SRC, int LP>
 struct KhgFwdRaw {
-    // Y: r, g, b of row a, then of row b, two pixels per 16-bit load.  C: r, g, b of the two pixel rows, four
-    // pixels per 32-bit load (bytes 0 and 2 are the two chroma sites).  PLANE: the pair of row a, the pair of row b.
-    // Y_BGR: the six bytes of two pixels as three 16-bit loads per row.  C_BGR: two 32-bit loads per row, one per site.
-    uint32_t w[SRC == KHG_SRC_PLANE ? 8 : 6];
+    // Per pair -- Y: r, g, b of row a, then of row b, two pixels per 16-bit load.  C: r, g, b of the two pixel rows,
+    // four pixels per 32-bit load (bytes 0 and 2 are the two chroma sites).  PLANE: the pair of row a, the pair of
+    // row b.  Y_BGR: the six bytes of two pixels as three 16-bit loads per row.  C_BGR: two 32-bit loads per row, one
+    // per site.  Y with two pairs per lane: one 32-bit load per plane and row holds both pairs.
+    uint32_t w[SRC == KHG_SRC_PLANE ? 8 * LP : (SRC == KHG_SRC_Y ? 6 : 6 * LP)];
 };
 
 KHG_DEV uint32_t khg_ld16(const uint8_t* p) { uint16_t v; __builtin_memcpy(&v, p, 2); return v; }
@@ -227,75 +266,110 @@ KHG_DEV void khg_fwd_row_offsets(const KhgFwdArgs& a, const KhgFwdPlane& pl, int
     ob = KHG_UNIFORM(khg_fwd_row_offset<SRC>(a, pl, khg_reflect(ya + 1, ph)));
 }
 
-// Where a lane's pair (x[2p], x[2p+1]) is read from: both samples reflected into the row (p may lie up to two pairs
+// Where a lane's pairs (x[2p], x[2p+1]) are read from: all samples reflected into the row (p may lie up to two pairs
 // outside the plane, and anywhere for lanes beyond the last strip, whose loads are not used).  The two reflected
-// columns are always neighbours; `col` is the lower one and `swap` says that it holds the odd sample.
+// columns of a pair are always neighbours; col[a] is the lower one and she / sho say where in the loaded window the
+// even and the odd sample sit.
+template <int LP>
 struct KhgLaneSrc {
-    uint32_t col;  // column offset of the load in elements of the source (planar RGB: pixels; BGR: bytes)
-    uint32_t she;  // planar RGB: bit position of the even sample's byte in the loaded word; others: nonzero = swapped
-    uint32_t sho;  // planar RGB: bit position of the odd sample's byte
+    uint32_t col[LP];  // column offset of the load in elements of the source (planar RGB: pixels; BGR: bytes)
+    uint32_t she[LP];  // planar RGB: bit position of the even sample's byte in the loaded word; others: nonzero = swapped
+    uint32_t sho[LP];  // planar RGB: bit position of the odd sample's byte
 };
 
-template <int SRC>
-KHG_DEV KhgLaneSrc khg_fwd_lane_src(int p, int pw)
+template <int SRC, int LP>
+KHG_DEV KhgLaneSrc<LP> khg_fwd_lane_src(int p0, int pw)
 {
-    const int ec = khg_reflect(2 * p, pw), oc = khg_reflect(2 * p + 1, pw);
-    const bool swap = ec > oc;
-    const uint32_t lo = (uint32_t)(swap ? oc : ec);
-    const uint32_t sh = SRC == KHG_SRC_Y ? 8u : 16u;  // distance of the pair's samples in the word: chroma sites are
-    KhgLaneSrc l;                                     // every second pixel (Colorspace.h:16-21)
-    l.col = SRC == KHG_SRC_C ? 2u * lo : SRC == KHG_SRC_Y_BGR ? 3u * lo : SRC == KHG_SRC_C_BGR ? 6u * lo : lo;
-    l.she = swap ? sh : 0u;
-    l.sho = swap ? 0u : sh;
+    KhgLaneSrc<LP> l;
+    if (SRC == KHG_SRC_Y && LP == 2) {
+        // one 4-byte window for the lane's four samples: reflection moves by one column per sample, so they lie
+        // within four columns; the window is pulled back into the row at its right end (pw >= 4)
+        int r[4], lo = pw;
+        for (int i = 0; i < 4; ++i) {
+            r[i] = khg_reflect(2 * p0 + i, pw);
+            lo = r[i] < lo ? r[i] : lo;
+        }
+        if (lo > pw - 4) lo = pw - 4;
+        for (int a = 0; a < LP; ++a) {
+            l.col[a] = (uint32_t)lo;
+            l.she[a] = 8u * (uint32_t)(r[2 * a] - lo);
+            l.sho[a] = 8u * (uint32_t)(r[2 * a + 1] - lo);
+        }
+        return l;
+    }
+    for (int a = 0; a < LP; ++a) {
+        const int p = p0 + a;
+        const int ec = khg_reflect(2 * p, pw), oc = khg_reflect(2 * p + 1, pw);
+        const bool swap = ec > oc;
+        const uint32_t lo = (uint32_t)(swap ? oc : ec);
+        const uint32_t sh = SRC == KHG_SRC_Y ? 8u : 16u;  // distance of the pair's samples in the word: chroma sites are
+                                                          // every second pixel (Colorspace.h:16-21)
+        l.col[a] = SRC == KHG_SRC_C ? 2u * lo : SRC == KHG_SRC_Y_BGR ? 3u * lo : SRC == KHG_SRC_C_BGR ? 6u * lo : lo;
+        l.she[a] = swap ? sh : 0u;
+        l.sho[a] = swap ? 0u : sh;
+    }
     return l;
 }
 
-// Two rows of the plane at row offsets oa, ob (khg_fwd_row_offsets), at the lane's column.  Offsets are 32-bit: a
+// Two rows of the plane at row offsets oa, ob (khg_fwd_row_offsets), at the lane's columns.  Offsets are 32-bit: a
 // plane has fewer than 2^31 samples.  Loads of 2 / 4 / 16 bytes at any 1 / 2 / 8-byte boundary.
-template <int SRC>
-KHG_DEV void khg_fwd_fetch(const KhgFwdArgs& a, const KhgFwdPlane& pl, KhgFwdRaw<SRC>& raw, uint32_t oa, uint32_t ob,
-                           uint32_t col)
+template <int SRC, int LP>
+KHG_DEV void khg_fwd_fetch(const KhgFwdArgs& a, const KhgFwdPlane& pl, KhgFwdRaw<SRC, LP>& raw, uint32_t oa0, uint32_t ob0,
+                           const KhgLaneSrc<LP>& ls)
 {
-    oa += col;
-    ob += col;
-    if constexpr (SRC == KHG_SRC_PLANE) {
-        __builtin_memcpy(&raw.w[0], pl.src + oa, 16);
-        __builtin_memcpy(&raw.w[4], pl.src + ob, 16);
-    } else if constexpr (SRC == KHG_SRC_Y) {
-        raw.w[0] = khg_ld16(a.r + oa); raw.w[1] = khg_ld16(a.g + oa); raw.w[2] = khg_ld16(a.b + oa);
-        raw.w[3] = khg_ld16(a.r + ob); raw.w[4] = khg_ld16(a.g + ob); raw.w[5] = khg_ld16(a.b + ob);
-    } else if constexpr (SRC == KHG_SRC_Y_BGR) {  // B G R B G R of two neighbouring pixels
-        raw.w[0] = khg_ld16(a.r + oa); raw.w[1] = khg_ld16(a.r + oa + 2); raw.w[2] = khg_ld16(a.r + oa + 4);
-        raw.w[3] = khg_ld16(a.r + ob); raw.w[4] = khg_ld16(a.r + ob + 2); raw.w[5] = khg_ld16(a.r + ob + 4);
-    } else if constexpr (SRC == KHG_SRC_C_BGR) {  // B G R (and one more byte) of two pixels two columns apart
-        raw.w[0] = khg_ld32(a.r + oa); raw.w[1] = khg_ld32(a.r + oa + 6);
-        raw.w[2] = khg_ld32(a.r + ob); raw.w[3] = khg_ld32(a.r + ob + 6);
-    } else {
+    if constexpr (SRC == KHG_SRC_Y && LP == 2) {
+        const uint32_t oa = oa0 + ls.col[0], ob = ob0 + ls.col[0];
         raw.w[0] = khg_ld32(a.r + oa); raw.w[1] = khg_ld32(a.g + oa); raw.w[2] = khg_ld32(a.b + oa);
         raw.w[3] = khg_ld32(a.r + ob); raw.w[4] = khg_ld32(a.g + ob); raw.w[5] = khg_ld32(a.b + ob);
+    } else {
+        KHG_UNROLL
+        for (int p = 0; p < LP; ++p) {
+            const uint32_t oa = oa0 + ls.col[p], ob = ob0 + ls.col[p];
+            uint32_t* w = &raw.w[(SRC == KHG_SRC_PLANE ? 8 : 6) * p];
+            if constexpr (SRC == KHG_SRC_PLANE) {
+                __builtin_memcpy(&w[0], pl.src + oa, 16);
+                __builtin_memcpy(&w[4], pl.src + ob, 16);
+            } else if constexpr (SRC == KHG_SRC_Y) {
+                w[0] = khg_ld16(a.r + oa); w[1] = khg_ld16(a.g + oa); w[2] = khg_ld16(a.b + oa);
+                w[3] = khg_ld16(a.r + ob); w[4] = khg_ld16(a.g + ob); w[5] = khg_ld16(a.b + ob);
+            } else if constexpr (SRC == KHG_SRC_Y_BGR) {  // B G R B G R of two neighbouring pixels
+                w[0] = khg_ld16(a.r + oa); w[1] = khg_ld16(a.r + oa + 2); w[2] = khg_ld16(a.r + oa + 4);
+                w[3] = khg_ld16(a.r + ob); w[4] = khg_ld16(a.r + ob + 2); w[5] = khg_ld16(a.r + ob + 4);
+            } else if constexpr (SRC == KHG_SRC_C_BGR) {  // B G R (and one more byte) of two pixels two columns apart
+                w[0] = khg_ld32(a.r + oa); w[1] = khg_ld32(a.r + oa + 6);
+                w[2] = khg_ld32(a.r + ob); w[3] = khg_ld32(a.r + ob + 6);
+            } else {
+                w[0] = khg_ld32(a.r + oa); w[1] = khg_ld32(a.g + oa); w[2] = khg_ld32(a.b + oa);
+                w[3] = khg_ld32(a.r + ob); w[4] = khg_ld32(a.g + ob); w[5] = khg_ld32(a.b + ob);
+            }
+        }
     }
 }
 
-// Samples (even, odd) of row rr (0: a, 1: b) of channel n (Y / plane: 0; chroma: 0 = Cb, 1 = Cr) as the f64 values
-// the transform runs on.  Main.cpp:200-202 widens u8 to double; Colorspace.h:11,19,20: products and sums left to right.
-template <int SRC>
-KHG_DEV void khg_fwd_samples(const KhgFwdRaw<SRC>& raw, const KhgLaneSrc& ls, int rr, int n, double& e, double& o)
+// Samples (even, odd) of pair p of the lane, row rr (0: a, 1: b), channel n (Y / plane: 0; chroma: 0 = Cb, 1 = Cr) as
+// the f64 values the transform runs on.  Main.cpp:200-202 widens u8 to double; Colorspace.h:11,19,20: products and
+// sums left to right.
+template <int SRC, int LP>
+KHG_DEV void khg_fwd_samples(const KhgFwdRaw<SRC, LP>& raw, const KhgLaneSrc<LP>& ls, int p, int rr, int n, double& e,
+                             double& o)
 {
+    const uint32_t she = ls.she[p], sho = ls.sho[p];
     if constexpr (SRC == KHG_SRC_PLANE) {
         double lo, hi;
-        __builtin_memcpy(&lo, &raw.w[4 * rr], 8);
-        __builtin_memcpy(&hi, &raw.w[4 * rr + 2], 8);
-        e = ls.she ? hi : lo;
-        o = ls.she ? lo : hi;
+        __builtin_memcpy(&lo, &raw.w[8 * p + 4 * rr], 8);
+        __builtin_memcpy(&hi, &raw.w[8 * p + 4 * rr + 2], 8);
+        e = she ? hi : lo;
+        o = she ? lo : hi;
     } else if constexpr (KHG_SRC_IS_BGR(SRC)) {
+        const uint32_t* w = &raw.w[6 * p];
         uint32_t pa, pb;  // (B, G, R) of the lower and of the upper pixel in bits 0-23
         if (SRC == KHG_SRC_Y_BGR) {
-            const uint32_t w0 = raw.w[3 * rr], w1 = raw.w[3 * rr + 1], w2 = raw.w[3 * rr + 2];
+            const uint32_t w0 = w[3 * rr], w1 = w[3 * rr + 1], w2 = w[3 * rr + 2];
             pa = w0 | (w1 << 16);
             pb = (w1 >> 8) | (w2 << 8);
         } else {
-            pa = raw.w[2 * rr];
-            pb = raw.w[2 * rr + 1];
+            pa = w[2 * rr];
+            pb = w[2 * rr + 1];
         }
         const double B0 = (double)(pa & 255u), G0 = (double)((pa >> 8) & 255u), R0 = (double)((pa >> 16) & 255u);
         const double B1 = (double)(pb & 255u), G1 = (double)((pb >> 8) & 255u), R1 = (double)((pb >> 16) & 255u);
@@ -310,14 +384,13 @@ KHG_DEV void khg_fwd_samples(const KhgFwdRaw<SRC>& raw, const KhgLaneSrc& ls, in
             va = R0 * 0.5 + G0 * -0.41869 + B0 * -0.08131;
             vb = R1 * 0.5 + G1 * -0.41869 + B1 * -0.08131;
         }
-        e = ls.she ? vb : va;
-        o = ls.she ? va : vb;
+        e = she ? vb : va;
+        o = she ? va : vb;
     } else {
-        const uint32_t r = raw.w[3 * rr], g = raw.w[3 * rr + 1], b = raw.w[3 * rr + 2];
-        const double R0 = (double)((r >> ls.she) & 255u), G0 = (double)((g >> ls.she) & 255u),
-                     B0 = (double)((b >> ls.she) & 255u);
-        const double R1 = (double)((r >> ls.sho) & 255u), G1 = (double)((g >> ls.sho) & 255u),
-                     B1 = (double)((b >> ls.sho) & 255u);
+        const uint32_t* w = &raw.w[SRC == KHG_SRC_Y && LP == 2 ? 0 : 6 * p];
+        const uint32_t r = w[3 * rr], g = w[3 * rr + 1], b = w[3 * rr + 2];
+        const double R0 = (double)((r >> she) & 255u), G0 = (double)((g >> she) & 255u), B0 = (double)((b >> she) & 255u);
+        const double R1 = (double)((r >> sho) & 255u), G1 = (double)((g >> sho) & 255u), B1 = (double)((b >> sho) & 255u);
         if (SRC == KHG_SRC_Y) {
             e = R0 * 0.299 + G0 * 0.587 + B0 * 0.114;
             o = R1 * 0.299 + G1 * 0.587 + B1 * 0.114;
@@ -331,30 +404,38 @@ KHG_DEV void khg_fwd_samples(const KhgFwdRaw<SRC>& raw, const KhgLaneSrc& ls, in
     }
 }
 
-// Per-thread tally of the symbols -1, 0, +1, which make up almost all detail-band symbols: counting them
-// in a register keeps 64 lanes from hammering one LDS word.  Bits 0-23: three 8-bit counters (a lane emits at most
-// four symbols per row pair of a segment), symbol q in byte 1 - q; bits 24-29: one `seen` bit per (symbol, output
-// stream), symbol q of stream t at bit 24 + 3 t + q + 1.  Both layouts make a symbol's word one instruction.
-// A lane's raster indices rise within each of its two output streams (rows k: low-half column, then high-half
-// column; rows hh+k: the same), so only the first hit of a symbol in a stream can lower the workgroup's
-// first-appearance index: one LDS atomic per bit, ever.
-typedef uint32_t KhgHot;
-
 // ---- quantiser (Compress.h:218-219) and symbol table counts (Huffman.h:110-139).
-// The symbols a lane emits for one row pair are quantised together: the common case -- every quotient is clear of a
-// rounding tie and every symbol is -1, 0 or +1 and has been seen in its stream before -- is straight-line code, and
-// everything else is collected behind two rarely taken branches.
+//
+// Per-thread tally of the symbols -1, 0, +1, which make up almost all detail-band symbols: counting them in a
+// register keeps 64 lanes from hammering one LDS word.  `cnt`: 8-bit counters, zeros in byte 0, -1 in byte 1, +1 in
+// byte 3 (a symbol's unit is one v_alignbyte of its two low bits), moved to the workgroup histogram every
+// KHG_TALLY_TRIPS trips.  `seen`: one bit per (symbol, output stream), bit 4 t + (q & 3).  A lane's raster indices
+// rise within each of its two output streams (rows k: low-half column, then high-half column; rows hh+k: the same),
+// so only the first hit of a symbol in a stream can lower the workgroup's first-appearance index: one LDS atomic per
+// bit, ever.  And once the workgroup histogram holds all three symbols at positions before the row a wave works on,
+// nothing that wave still emits can lower them: from then on (`done`) the wave only counts.
 
-// q = round(c / div) from rdiv = RN(1/div), when that is safe: t = c * rdiv is within 2^-51 (relative) of the exact
-// quotient, far less than 1e-5 for every |t| that can become a symbol, so both round to the same integer unless
-// t sits within 1e-5 of a half-integer (then, and for NaN and infinity, the caller divides).  Away from ties
-// round-to-nearest-even and round-half-away agree.  A huge finite t passes and saturates q, which is out of the
-// symbol range and fails the job like the division would.
-KHG_DEV bool khg_quant_try(double c, double rdiv, int* q)
+// Unit of symbol q in -1..1 in the 8-bit tallies (for other q: byte 2 or an alias of these, unused).
+#ifndef KHG_SIM
+KHG_DEV uint32_t khg_hot_unit(int q) { return __builtin_amdgcn_alignbyte(1u, 1u, (uint32_t)q); }
+#else
+KHG_DEV uint32_t khg_hot_unit(int q) { return (uint32_t)(0x0000000100000001ull >> (8u * ((uint32_t)q & 3u))); }
+#endif
+KHG_DEV uint32_t khg_hot_seen(int q, int stream) { return (1u << (4 * stream)) << ((uint32_t)q & 3u); }
+
+// q = round(c / div) for c = x scaled by the column pass (DWT.h:45-50: even samples x / a, odd samples x * a), from
+// rdiv = RN(1/div) with the scale folded in (khg_fwd_rdiv_entry), when that is safe: t = x * rdiv is within a few
+// 2^-53 (relative) of the exact quotient, far less than 1e-5 for every |t| that can become a symbol, so both round to
+// the same integer unless t sits within 1e-5 of a half-integer (then, and for NaN and infinity, the caller scales and
+// divides as the reference does).  Away from ties round-to-nearest-even and round-half-away agree.  A huge finite t
+// passes and saturates q, which is out of the symbol range and fails the job like the division would.
+// nhi: the high word of the rounded quotient as a double (|n| <= 1 exactly when its low 31 bits are <= 0x3FF00000).
+KHG_DEV bool khg_quant_try(double x, double rdiv, int* q, uint32_t* nhi)
 {
-    const double t = c * rdiv;
+    const double t = x * rdiv;
     const double n = __builtin_rint(t);
     *q = khg_f2i(n);
+    *nhi = khg_hi32(n);
     return fabs(t - n) < 0.49999;
 }
 
@@ -366,40 +447,46 @@ KHG_DEV int khg_quant_divide(const KhgFwdArgs& a, const KhgFwdPlane& pl, double 
     return (int)n;
 }
 
-// Tally words of a hot symbol q = q1 - 1 in -1..1: its 8-bit counter's unit, and its seen bit in output stream
-// `stream`.  For other q1 the results are meaningless (and unused).
+// Table entry of band `band` at position (x, y): 1 / divisor, times the column pass's scale of that band's samples
+// (bands whose rows are low-pass rows -- 0, 1 and 4 -- divide by a, the others multiply by it).  Level-1 LL values
+// are stored, not quantised, and keep the exact scaling.
+// khg_quant_try only needs it to a relative 1e-9 or so (an entry that is off declines more quotients or fewer,
+// never gives another symbol), so the reciprocal is the hardware's estimate (about 23 bits) and two Newton steps
+// instead of a division: a workgroup tabulates some 1600 to 2300 entries before its first row.
 #ifndef KHG_SIM
-KHG_DEV uint32_t khg_hot_unit(uint32_t q1) { return __builtin_amdgcn_alignbyte(0u, 0x10000u, q1); }  // 0x10000 >> 8 (q1 & 3)
+KHG_DEV double khg_recip_approx(double d)
+{
+    double r = __builtin_amdgcn_rcp(d);
+    r = khg_fma(khg_fma(-d, r, 1.0), r, r);
+    return khg_fma(khg_fma(-d, r, 1.0), r, r);
+}
 #else
-KHG_DEV uint32_t khg_hot_unit(uint32_t q1) { return 0x10000u >> (8u * (q1 & 3u)); }
+KHG_DEV double khg_recip_approx(double d) { return 1.0 / d; }
 #endif
-KHG_DEV uint32_t khg_hot_seen(uint32_t q1, int stream) { return (1u << (24 + 3 * stream)) << (q1 & 31u); }
+KHG_DEV double khg_fwd_rdiv_entry(const KhgQuant& q, int band, int x, int y, int lvl)
+{
+    const double rd = khg_recip_approx(khg_divisor(q, band, x, y, lvl));
+    const bool even = band == 0 || band == 1 || band == 4;
+    return even ? rd * (1 / KHG_SCALE_A) : rd * KHG_SCALE_A;
+}
 
-// Count one symbol of a row pair that the straight-line path could not finish (it holds a symbol other than -1, 0,
-// +1, or the first appearance of one of those in its stream).  Returns the symbol to store (0 when out of range).
+// Count one symbol that the straight-line path could not finish (the lane's row pair holds a symbol other than -1,
+// 0, +1, or the first appearance of one of those in its stream).  Returns the symbol to store (0 when out of range).
 template <int LHIST>
-KHG_DEV int khg_count_rare(const KhgFwdArgs& a, const KhgFwdPlane& pl, uint32_t* lcnt, uint32_t* lfirst, KhgHot& hot, int q,
-                           int stream, uint32_t raster)
+KHG_DEV int khg_count_rare(const KhgFwdArgs& a, const KhgFwdPlane& pl, uint32_t* lcnt, uint32_t* lfirst, uint32_t& cnt,
+                           uint32_t& seen, int q, int stream, uint32_t raster)
 {
     const int lh = LHIST == 256 ? 256 : a.lhist;  // bins in use, centred in the LHIST there is room for
-    const uint32_t q1 = (uint32_t)(q + 1);
-    if (q1 <= 2u) {
-        hot += khg_hot_unit(q1);
-        const uint32_t bit = khg_hot_seen(q1, stream);
-        if (!(hot & bit)) {
-            hot |= bit;
-            khg_lds_min(&lfirst[q + LHIST / 2], raster);
-        }
-        return q;
-    }
     if ((unsigned)(q + KHG_SYM_BIAS) >= 2u * KHG_SYM_BIAS) {
         khg_set_status(a.status, -4);
         q = 0;  // stored and counted as a zero; the job fails with KHG_ERR_RANGE
-        hot += khg_hot_unit(1u);
-        const uint32_t bit = khg_hot_seen(1u, stream);
-        if (!(hot & bit)) {
-            hot |= bit;
-            khg_lds_min(&lfirst[LHIST / 2], raster);
+    }
+    if ((uint32_t)(q + 1) <= 2u) {
+        cnt += khg_hot_unit(q);
+        const uint32_t bit = khg_hot_seen(q, stream);
+        if (!(seen & bit)) {
+            seen |= bit;
+            khg_lds_min(&lfirst[q + LHIST / 2], raster);
         }
         return q;
     }
@@ -414,131 +501,203 @@ KHG_DEV int khg_count_rare(const KhgFwdArgs& a, const KhgFwdPlane& pl, uint32_t*
     return q;
 }
 
-// NS coefficients c[i] of one lane and row pair, in raster order within each output stream: band[i], reciprocal
-// divisor rd[i], position (y[i], x[i]) -- used only off the fast path -- and byte offset so + boff[i] in the symbol
-// plane.  Quantises, stores and counts them.
-template <int NS, int LHIST>
-KHG_DEV void khg_quant_emit(const KhgFwdArgs& a, const KhgFwdPlane& pl, uint32_t* lcnt, uint32_t* lfirst, KhgHot& hot,
-                            const double* c, const double* rd, const int* band, const int* stream, const int* y,
-                            const int* x, uint32_t so, const uint32_t* boff)
+// A lane's 8-bit tallies into the workgroup histogram.
+template <int LHIST>
+KHG_DEV void khg_tally_flush(uint32_t* lcnt, uint32_t& cnt)
 {
-    int q[NS];
-    bool clear = true;
-    KHG_UNROLL
-    for (int i = 0; i < NS; ++i) clear = khg_quant_try(c[i], rd[i], &q[i]) && clear;
-    if (!clear) {  // near a tie, not finite: the reference's own division decides
-        KHG_UNROLL
-        for (int i = 0; i < NS; ++i) {
-            int qi;
-            if (!khg_quant_try(c[i], rd[i], &qi)) q[i] = khg_quant_divide(a, pl, c[i], band[i], x[i], y[i]);
-        }
-    }
-    uint32_t units = 0, seen = 0, top = 0;
-    KHG_UNROLL
-    for (int i = 0; i < NS; ++i) {
-        const uint32_t q1 = (uint32_t)(q[i] + 1);
-        top = q1 > top ? q1 : top;
-        units += khg_hot_unit(q1);
-        seen |= khg_hot_seen(q1, stream[i]);
-    }
-    if (top <= 2u && (seen & ~hot) == 0) {  // all of them -1, 0 or +1 and seen in their streams before
-        hot += units;
-    } else {
-        KHG_UNROLL
-        for (int i = 0; i < NS; ++i)
-            q[i] = khg_count_rare<LHIST>(a, pl, lcnt, lfirst, hot, q[i], stream[i], (so + boff[i]) >> 1);
-    }
-    KHG_UNROLL
-    for (int i = 0; i < NS; ++i) *(int16_t*)((char*)pl.sym + (so + boff[i])) = (int16_t)q[i];
+    const uint32_t c0 = cnt & 0xFFu, cm = (cnt >> 8) & 0xFFu, cp = cnt >> 24;
+    if (c0) khg_lds_add(&lcnt[LHIST / 2], c0);
+    if (cm) khg_lds_add(&lcnt[LHIST / 2 - 1], cm);
+    if (cp) khg_lds_add(&lcnt[LHIST / 2 + 1], cp);
+    cnt = 0;
 }
 
-// Finished, unscaled outputs (s2, d2) of row pair k of the lane's low-half column (L) and high-half column (H):
-// scale, store / quantise.  rd: this position's reciprocal divisors per band slot; so, llo: byte offsets of
-// position (k, pair) in the symbol plane and in the LL buffer.
-template <int LEVEL, int LHIST>
-KHG_DEV void khg_col_emit(const KhgFwdArgs& a, const KhgFwdPlane& pl, uint32_t* lcnt, uint32_t* lfirst, KhgHot& hot,
-                          int pair, int k, double s2L, double d2L, double s2H, double d2H, const double* rd, uint32_t so,
-                          uint32_t llo)
+// Finished, unscaled outputs (s2, d2) of row pair k of the low-half column (L) and high-half column (H) of the
+// lane's LP pairs (the first is pair `pair`): scale, store / quantise, count.  rd[s][p]: reciprocal divisors per band
+// slot and pair (khg_fwd_rdiv_entry); so, llo: byte offsets of position (k, pair) in the symbol plane and in the LL
+// buffer; done: nothing this wave emits from here on can lower the first-appearance index of -1, 0 or +1.
+// Nothing is stored here: llv receives the level-1 LL values, words the symbols of each band slot (two pairs per
+// lane: both in one word), and the result says whether the symbols are to be stored (see the caller).
+template <int LEVEL, int LP, int LHIST>
+KHG_DEV bool khg_col_emit(const KhgFwdArgs& a, const KhgFwdPlane& pl, uint32_t* lcnt, uint32_t* lfirst, uint32_t& cnt,
+                          uint32_t& seen, bool done, int pair, int k, const double* s2L, const double* d2L,
+                          const double* s2H, const double* d2H, const double (*rd)[LP], uint32_t so, double* llv,
+                          uint32_t* words)
 {
     const int hh = pl.ph / 2, hw = pl.pw / 2;
-    const double loL = khg_fwd_scale_even(s2L), hiL = khg_fwd_scale_odd(d2L);
-    const double loH = khg_fwd_scale_even(s2H), hiH = khg_fwd_scale_odd(d2H);
     if (pl.coef) {
-        const uint32_t c0 = (uint32_t)k * (uint32_t)pl.coef_pitch + (uint32_t)pair;
-        const uint32_t c1 = (uint32_t)(hh + k) * (uint32_t)pl.coef_pitch + (uint32_t)pair;
-        pl.coef[c0] = loL;
-        pl.coef[c0 + (uint32_t)hw] = loH;
-        pl.coef[c1] = hiL;
-        pl.coef[c1 + (uint32_t)hw] = hiH;
-    }
-    const bool emit = k >= pl.emit_k0 && k < pl.emit_k1;
-    const uint32_t right = 2u * (uint32_t)hw, down = 2u * (uint32_t)hh * (uint32_t)pl.sym_pitch;
-    if (LEVEL == 1) {  // bands LH(4) HL(5) HH(6) are final, LL feeds level 2 (Compress.h:154-160)
-        *(double*)((char*)pl.ll + llo) = loL;
-        if (emit) {
-            const double c[3] = {loH, hiL, hiH};
-            const int band[3] = {4, 5, 6}, stream[3] = {0, 1, 1};
-            const int y[3] = {k, hh + k, hh + k}, x[3] = {hw + pair, pair, hw + pair};
-            const uint32_t boff[3] = {right, down, down + right};
-            khg_quant_emit<3, LHIST>(a, pl, lcnt, lfirst, hot, c, rd, band, stream, y, x, so, boff);
+        KHG_UNROLL
+        for (int p = 0; p < LP; ++p) {
+            const uint32_t c0 = (uint32_t)k * (uint32_t)pl.coef_pitch + (uint32_t)(pair + p);
+            const uint32_t c1 = (uint32_t)(hh + k) * (uint32_t)pl.coef_pitch + (uint32_t)(pair + p);
+            pl.coef[c0] = khg_fwd_scale_even(s2L[p]);
+            pl.coef[c0 + (uint32_t)hw] = khg_fwd_scale_even(s2H[p]);
+            pl.coef[c1] = khg_fwd_scale_odd(d2L[p]);
+            pl.coef[c1 + (uint32_t)hw] = khg_fwd_scale_odd(d2H[p]);
         }
-    } else if (emit) {  // bands 0..3
-        const double c[4] = {loL, loH, hiL, hiH};
-        const int band[4] = {0, 1, 2, 3}, stream[4] = {0, 0, 1, 1};
-        const int y[4] = {k, k, hh + k, hh + k}, x[4] = {pair, hw + pair, pair, hw + pair};
-        const uint32_t boff[4] = {0, right, down, down + right};
-        khg_quant_emit<4, LHIST>(a, pl, lcnt, lfirst, hot, c, rd, band, stream, y, x, so, boff);
     }
+    if (LEVEL == 1) {  // LL feeds level 2 (Compress.h:112-114)
+        KHG_UNROLL
+        for (int p = 0; p < LP; ++p) llv[p] = khg_fwd_scale_even(s2L[p]);
+    }
+    if (!(k >= pl.emit_k0 && k < pl.emit_k1)) return false;
+    // Bands of this level (Compress.h:154-160): LL (level 2 only: band 0), then the three detail bands -- high-half
+    // column of low-pass row k, low-half and high-half column of high-pass row hh + k.
+    enum { NB = LEVEL == 1 ? 3 : 4, B0 = LEVEL == 1 ? 4 : 0, D0 = LEVEL == 1 ? 0 : 1, NS = NB * LP };
+    const uint32_t right = 2u * (uint32_t)hw, down = 2u * (uint32_t)hh * (uint32_t)pl.sym_pitch;
+    const uint32_t boff[4] = {0, right, down, down + right};  // of slot s: boff[s + 4 - NB]
+    int q[NB][LP];
+    uint32_t nhi[NB][LP];
+    bool clear = true;
+    KHG_UNROLL
+    for (int s = 0; s < NB; ++s) {
+        const int b4 = s + 4 - NB;  // 0 LL, 1 high-half of row k, 2 low-half of row hh + k, 3 high-half of row hh + k
+        KHG_UNROLL
+        for (int p = 0; p < LP; ++p) {
+            const double x = b4 == 0 ? s2L[p] : b4 == 1 ? s2H[p] : b4 == 2 ? d2L[p] : d2H[p];
+            clear = khg_quant_try(x, rd[s][p], &q[s][p], &nhi[s][p]) && clear;
+        }
+    }
+    if (!clear) {  // near a tie, not finite: the reference's own scaling, division and rounding decide
+        KHG_UNROLL
+        for (int s = 0; s < NB; ++s) {
+            const int b4 = s + 4 - NB;
+            KHG_UNROLL
+            for (int p = 0; p < LP; ++p) {
+                const double x = b4 == 0 ? s2L[p] : b4 == 1 ? s2H[p] : b4 == 2 ? d2L[p] : d2H[p];
+                int qi;
+                uint32_t ni;
+                if (!khg_quant_try(x, rd[s][p], &qi, &ni)) {
+                    const double c = b4 <= 1 ? khg_fwd_scale_even(x) : khg_fwd_scale_odd(x);
+                    q[s][p] = khg_quant_divide(a, pl, c, B0 + s, ((b4 & 1) ? hw : 0) + pair + p, (b4 >= 2 ? hh : 0) + k);
+                }
+            }
+        }
+    }
+    if (LEVEL == 2) {  // LL symbols spread over hundreds of values: straight to the histograms
+        KHG_UNROLL
+        for (int p = 0; p < LP; ++p) {
+            int v = q[0][p];
+            if ((unsigned)(v + KHG_SYM_BIAS) >= 2u * KHG_SYM_BIAS) {
+                khg_set_status(a.status, -4);
+                v = 0;  // stored and counted as a zero; the job fails with KHG_ERR_RANGE
+            }
+            const uint32_t raster = (so + 2u * (uint32_t)p) >> 1;
+            if ((unsigned)(v + a.lhist / 2) < (unsigned)a.lhist) {
+                khg_lds_add(&lcnt[v + LHIST / 2], 1u);
+                khg_lds_min(&lfirst[v + LHIST / 2], raster);
+            } else {
+                khg_atomic_add(&pl.hist_cnt[v + KHG_SYM_BIAS], 1u);
+                khg_atomic_min(&pl.hist_first[v + KHG_SYM_BIAS], raster);
+            }
+            q[0][p] = v;
+        }
+    }
+    // detail symbols: all of them -1, 0 or +1 (and none of them new to its stream): count in the register
+    uint32_t any = 0, units = 0, sn = 0;
+    KHG_UNROLL
+    for (int s = D0; s < NB; ++s)
+        KHG_UNROLL
+        for (int p = 0; p < LP; ++p) {
+            any |= nhi[s][p];
+            units += khg_hot_unit(q[s][p]);
+        }
+    bool fast = clear && (any & 0x7FFFFFFFu) <= 0x3FF00000u;
+    if (!done) {
+        KHG_UNROLL
+        for (int s = D0; s < NB; ++s)
+            KHG_UNROLL
+            for (int p = 0; p < LP; ++p) sn |= khg_hot_seen(q[s][p], s + 4 - NB >= 2);
+        fast = fast && (sn & ~seen) == 0;
+    }
+    if (fast) {
+        cnt += units;
+    } else {
+        KHG_UNROLL
+        for (int s = D0; s < NB; ++s)
+            KHG_UNROLL
+            for (int p = 0; p < LP; ++p)
+                q[s][p] = khg_count_rare<LHIST>(a, pl, lcnt, lfirst, cnt, seen, q[s][p], s + 4 - NB >= 2,
+                                                (so + boff[s + 4 - NB] + 2u * (uint32_t)p) >> 1);
+    }
+    KHG_UNROLL
+    for (int s = 0; s < NB; ++s) words[s] = LP == 2 ? khg_pack16(q[s][0], q[s][LP - 1]) : (uint32_t)q[s][0];
+    return true;
+}
+
+// Have all of -1, 0, +1 appeared in the workgroup's histograms of the NP planes before raster index `before`?
+template <int NP, int LHIST>
+KHG_DEV bool khg_hot_done(uint32_t (*lfirst)[LHIST], uint32_t before)
+{
+    bool all = true;
+    for (int n = 0; n < NP; ++n)
+        for (int v = -1; v <= 1; ++v) all = all && lfirst[n][LHIST / 2 + v] < before;
+    return all;
 }
 
 // One workgroup: KHG_WG_STRIPS adjacent strips (one per wave) over one segment of rows of NP planes of equal
-// geometry (NP = 2: Cb and Cr from the same pixels).  wgl = workgroup index within the plane's grid.
-template <int SRC, int LEVEL, int NP>
-KHG_DEV void khg_fwd_wg_body(const KhgFwdArgs& a, const KhgFwdPlane* pls, int wgl, KhgFwdSmem<LEVEL, NP>& sh)
+// geometry (NP = 2: Cb and Cr from the same pixels), LP pairs per lane.  wgl = workgroup index within the plane's grid.
+template <int SRC, int LEVEL, int NP, int LP>
+KHG_DEV void khg_fwd_wg_body(const KhgFwdArgs& a, const KhgFwdPlane* pls, int wgl, KhgFwdSmem<LEVEL, NP, LP>& sh)
 {
-    typedef KhgFwdSmem<LEVEL, NP> SM;
+    typedef KhgFwdSmem<LEVEL, NP, LP> SM;
+    enum { SP = KHG_STRIP_PAIRS_LP(LP) };
     const KhgFwdPlane& g = pls[0];  // geometry (shared by the NP planes)
     const int swg = wgl % g.nstrip_wg, seg = wgl / g.nstrip_wg;
-    const int np = g.pw / 2, hh = g.ph / 2, hw = g.pw / 2;
+    const int np = g.pw / 2;
     int r0, r1;
     khg_segment_rows(g.row_begin, g.row_end, g.nseg, seg, &r0, &r1);
     const int k0 = r0 / 2, k1 = r1 / 2;
-    const int P0 = KHG_STRIP_PAIRS * KHG_WG_STRIPS * swg;  // first output pair of the workgroup
+    const int P0 = SP * KHG_WG_STRIPS * swg;  // first output pair of the workgroup
+    // byte offsets in the symbol plane from position (k, pair) to (k, w/2 + pair) and to (h/2 + k, pair)
+    const uint32_t right = 2u * (uint32_t)(g.pw / 2), down = 2u * (uint32_t)(g.ph / 2) * (uint32_t)g.sym_pitch;
 
-    KhgLift colL[NP][KHG_NSLOT(256)], colH[NP][KHG_NSLOT(256)];
-    KhgHot hots[NP][KHG_NSLOT(256)];
-    KhgFwdRaw<SRC> raws[KHG_NSLOT(256)];
-    KhgLaneSrc lsrc[KHG_NSLOT(256)];
-    int pairs[KHG_NSLOT(256)];     // the lane's pair, clamped to the strip's output pairs
-    bool outl[KHG_NSLOT(256)];     // the lane outputs its pair
+    KhgLift colL[NP][LP][KHG_NSLOT(256)], colH[NP][LP][KHG_NSLOT(256)];
+    uint32_t cnts[NP][KHG_NSLOT(256)], seens[NP][KHG_NSLOT(256)];
+    int dones[KHG_NSLOT(256)];     // the wave only counts -1, 0, +1 from here on (see khg_hot_done)
+    KhgFwdRaw<SRC, LP> raws[KHG_NSLOT(256)];
+#ifdef KHG_EXP_PF2
+    KhgFwdRaw<SRC, LP> raws2[KHG_NSLOT(256)];  // the rows of the trip after next
+#endif
+    KhgLaneSrc<LP> lsrc[KHG_NSLOT(256)];
+    int pairs[KHG_NSLOT(256)];     // the lane's first pair, clamped to the strip's output pairs
+    bool outl[KHG_NSLOT(256)];     // the lane outputs its pairs
     uint32_t symo[KHG_NSLOT(256)], llo[KHG_NSLOT(256)];  // byte offsets of (k, pair) in the symbol plane / LL buffer
-    // values of the row pass that cross an exchange: [row a / b][plane]
-    double E[2][NP][KHG_NSLOT(256)], O[2][NP][KHG_NSLOT(256)], D1[2][NP][KHG_NSLOT(256)], S1[2][NP][KHG_NSLOT(256)],
-        D2[2][NP][KHG_NSLOT(256)], X[2][NP][KHG_NSLOT(256)];
+    // values of the row pass that cross an exchange: [row a / b][plane][pair]
+    double E[2][NP][LP][KHG_NSLOT(256)], O[2][NP][LP][KHG_NSLOT(256)], D1[2][NP][LP][KHG_NSLOT(256)],
+        S1[2][NP][LP][KHG_NSLOT(256)], D2[2][NP][LP][KHG_NSLOT(256)], X[2][NP][KHG_NSLOT(256)];
 
     KHG_FOR_THREADS(256)
     {
         if (a.prof && tid == 0) khg_atomic_max64(&a.prof->prof_not_start, ~khg_clock());
         const int lane = tid & 63, s = swg * KHG_WG_STRIPS + KHG_UNIFORM(tid >> 6);
-        // strip s outputs pairs 60 s .. 60 s + 59 (those inside the plane); its lanes hold pairs 60 s - 2 .. 60 s + 61
-        const int v0 = KHG_STRIP_PAIRS * s, v1 = v0 + KHG_STRIP_PAIRS < np ? v0 + KHG_STRIP_PAIRS : np;
-        const int p = v0 - 2 + lane;
+        // strip s outputs pairs SP s .. SP s + SP - 1 (those inside the plane); its lanes hold pairs SP s - 2 .. SP s + SP + 1
+        const int v0 = SP * s, v1 = v0 + SP < np ? v0 + SP : np;
+        const int p = v0 - 2 + LP * lane;
         outl[KHG_SLOT] = p >= v0 && p < v1;  // a wave beyond the last strip loads and computes without output
-        pairs[KHG_SLOT] = p < v0 ? v0 : (p > v0 + KHG_STRIP_PAIRS - 1 ? v0 + KHG_STRIP_PAIRS - 1 : p);
-        lsrc[KHG_SLOT] = khg_fwd_lane_src<SRC>(p, g.pw);
+        pairs[KHG_SLOT] = p < v0 ? v0 : (p > v0 + SP - LP ? v0 + SP - LP : p);
+        lsrc[KHG_SLOT] = khg_fwd_lane_src<SRC, LP>(p, g.pw);
         // the first trip finishes row pair k0 - 4 (nothing is stored before k0; the offsets just run along)
         symo[KHG_SLOT] = 2u * ((uint32_t)(k0 - 4) * (uint32_t)g.sym_pitch + (uint32_t)pairs[KHG_SLOT]);
         llo[KHG_SLOT] = 8u * ((uint32_t)(k0 - 4) * (uint32_t)g.ll_pitch + (uint32_t)pairs[KHG_SLOT]);
         const KhgLift z = {0, 0, 0, 0, 0};
         for (int n = 0; n < NP; ++n) {
-            colL[n][KHG_SLOT] = z;
-            colH[n][KHG_SLOT] = z;
-            hots[n][KHG_SLOT] = 0;
+            for (int q = 0; q < LP; ++q) {
+                colL[n][q][KHG_SLOT] = z;
+                colH[n][q][KHG_SLOT] = z;
+            }
+            cnts[n][KHG_SLOT] = 0;
+            seens[n][KHG_SLOT] = 0;
         }
+        dones[KHG_SLOT] = 0;
         // rows of the first trip
         uint32_t foa, fob;
         khg_fwd_row_offsets<SRC>(a, g, k0 - 2, foa, fob);
-        khg_fwd_fetch<SRC>(a, g, raws[KHG_SLOT], foa, fob, lsrc[KHG_SLOT].col);
+        khg_fwd_fetch<SRC, LP>(a, g, raws[KHG_SLOT], foa, fob, lsrc[KHG_SLOT]);
+#ifdef KHG_EXP_PF2
+        khg_fwd_row_offsets<SRC>(a, g, k0 - 1, foa, fob);
+        khg_fwd_fetch<SRC, LP>(a, g, raws2[KHG_SLOT], foa, fob, lsrc[KHG_SLOT]);
+#endif
         const int lh = LEVEL == 1 ? (int)SM::LHIST : a.lhist, l0 = SM::LHIST_BIAS - lh / 2;  // the bins in use
         for (int n = 0; n < NP; ++n)
             for (int i = l0 + tid; i < l0 + lh; i += 256) {
@@ -547,110 +706,224 @@ KHG_DEV void khg_fwd_wg_body(const KhgFwdArgs& a, const KhgFwdPlane* pls, int wg
             }
         // The divisor depends on the band and on x + y only (Compress.h:215-218); pair P0 + i at row pair k sits
         // on diagonal u = i + (k - k0) of each band this workgroup emits.
-        const int nu = KHG_WG_STRIPS * KHG_STRIP_PAIRS + (k1 - k0);
+        const int hh = g.ph / 2, hw = g.pw / 2;
+        const int nu = KHG_WG_STRIPS * SP + (k1 - k0);
         for (int e = tid; e < SM::NBAND * nu; e += 256) {
             int s2 = e / nu, u = e - s2 * nu;
             int band = LEVEL == 1 ? 4 + s2 : s2;
             int by = (LEVEL == 1 ? (band >= 5) : (band >= 2)) ? hh : 0;
             int bx = (LEVEL == 1 ? (band != 5) : (band & 1)) ? hw : 0;
-            sh.rdiv[s2 * KHG_RD_N + KHG_RD_PAD + u] = 1.0 / khg_divisor(g.q, band, bx + P0 + u, by + k0, a.lvl);
+            sh.rdiv[s2 * SM::RD_N + KHG_RD_PAD + u] = khg_fwd_rdiv_entry(g.q, band, bx + P0 + u, by + k0, a.lvl);
         }
     }
     KHG_BARRIER();
 
     // Row pairs k0-2 .. k1+1 are fed; the column pipeline hands back pair j-2 when pair j goes in.
-    for (int j = k0 - 2; j <= k1 + 1; ++j) {
+#if !defined(KHG_SIM) && defined(KHG_FWD_UNROLL2)
+    // Developer option: an even number of trips (the one too many finishes row pair k1, which is not output), two per
+    // pass of the compiled loop, so that the column states return to their registers every second trip instead of
+    // being copied back at the end of every one (16 64-bit moves per trip and sample pair).  Measured: twice the
+    // code, no gain.
+    const int jend = k1 + 1 + ((k1 - k0) & 1);
+#else
+    const int jend = k1 + 1;
+#endif
+#ifndef KHG_SIM
+    // a wave whose strip lies beyond the plane has nothing to do until the workgroup's last barrier
+    const bool idle = SP * (swg * KHG_WG_STRIPS + KHG_UNIFORM((int)(threadIdx.x >> 6))) >= np;
+#else
+    const bool idle = false;
+#endif
+    auto trip = [&](const int j) __attribute__((always_inline)) {
         // source rows of the next trip (the same for every thread)
         uint32_t noa, nob;
+#ifdef KHG_EXP_PF2
+        khg_fwd_row_offsets<SRC>(a, g, j + 2, noa, nob);
+#else
         khg_fwd_row_offsets<SRC>(a, g, j + 1, noa, nob);
+#endif
+#ifdef KHG_EXP_FAKELOAD  // developer experiment: every trip reads the same two rows
+        noa = 0; nob = 0;
+#endif
         KHG_FOR_THREADS(256)
         {
             KHG_UNROLL
             for (int rr = 0; rr < 2; ++rr)
                 KHG_UNROLL
                 for (int n = 0; n < NP; ++n)
-                    khg_fwd_samples<SRC>(raws[KHG_SLOT], lsrc[KHG_SLOT], rr, n, E[rr][n][KHG_SLOT], O[rr][n][KHG_SLOT]);
+                    KHG_UNROLL
+                    for (int p = 0; p < LP; ++p)
+                        khg_fwd_samples<SRC, LP>(raws[KHG_SLOT], lsrc[KHG_SLOT], p, rr, n, E[rr][n][p][KHG_SLOT],
+                                                 O[rr][n][p][KHG_SLOT]);
             // next trip's rows: in flight during this trip's arithmetic (unconditional, also after the last
             // trip, where the rows are reflected back into the plane and the loads are simply not used: a
             // condition here would make the loads land in other registers and cost a wait and copies per trip)
-            khg_fwd_fetch<SRC>(a, g, raws[KHG_SLOT], noa, nob, lsrc[KHG_SLOT].col);
+#ifdef KHG_EXP_PF2
+            raws[KHG_SLOT] = raws2[KHG_SLOT];
+            khg_fwd_fetch<SRC, LP>(a, g, raws2[KHG_SLOT], noa, nob, lsrc[KHG_SLOT]);
+#else
+            khg_fwd_fetch<SRC, LP>(a, g, raws[KHG_SLOT], noa, nob, lsrc[KHG_SLOT]);
+#endif
         }
         // predict 1: d1[p] = o[p] + P1 * (e[p] + e[p+1])
         for (int rr = 0; rr < 2; ++rr)
-            for (int n = 0; n < NP; ++n) KHG_LANE_NEXT(X[rr][n], E[rr][n])
+            for (int n = 0; n < NP; ++n) KHG_LANE_NEXT(X[rr][n], E[rr][n][0])
         KHG_FOR_THREADS(256)
         {
             KHG_UNROLL
             for (int rr = 0; rr < 2; ++rr)
                 KHG_UNROLL
                 for (int n = 0; n < NP; ++n)
-                    D1[rr][n][KHG_SLOT] = O[rr][n][KHG_SLOT] + KHG_P1 * (E[rr][n][KHG_SLOT] + X[rr][n][KHG_SLOT]);
+                    KHG_UNROLL
+                    for (int p = 0; p < LP; ++p) {
+                        const double nx = p + 1 < LP ? E[rr][n][p + 1 < LP ? p + 1 : 0][KHG_SLOT] : X[rr][n][KHG_SLOT];
+                        D1[rr][n][p][KHG_SLOT] = O[rr][n][p][KHG_SLOT] + KHG_P1 * (E[rr][n][p][KHG_SLOT] + nx);
+                    }
         }
         // update 1: s1[p] = e[p] + U1 * (d1[p-1] + d1[p])
         for (int rr = 0; rr < 2; ++rr)
-            for (int n = 0; n < NP; ++n) KHG_LANE_PREV(X[rr][n], D1[rr][n])
+            for (int n = 0; n < NP; ++n) KHG_LANE_PREV(X[rr][n], D1[rr][n][LP - 1])
         KHG_FOR_THREADS(256)
         {
             KHG_UNROLL
             for (int rr = 0; rr < 2; ++rr)
                 KHG_UNROLL
                 for (int n = 0; n < NP; ++n)
-                    S1[rr][n][KHG_SLOT] = E[rr][n][KHG_SLOT] + KHG_U1 * (X[rr][n][KHG_SLOT] + D1[rr][n][KHG_SLOT]);
+                    KHG_UNROLL
+                    for (int p = 0; p < LP; ++p) {
+                        const double pv = p > 0 ? D1[rr][n][p > 0 ? p - 1 : 0][KHG_SLOT] : X[rr][n][KHG_SLOT];
+                        S1[rr][n][p][KHG_SLOT] = E[rr][n][p][KHG_SLOT] + KHG_U1 * (pv + D1[rr][n][p][KHG_SLOT]);
+                    }
         }
         // predict 2: d2[p] = d1[p] + P2 * (s1[p] + s1[p+1])
         for (int rr = 0; rr < 2; ++rr)
-            for (int n = 0; n < NP; ++n) KHG_LANE_NEXT(X[rr][n], S1[rr][n])
+            for (int n = 0; n < NP; ++n) KHG_LANE_NEXT(X[rr][n], S1[rr][n][0])
         KHG_FOR_THREADS(256)
         {
             KHG_UNROLL
             for (int rr = 0; rr < 2; ++rr)
                 KHG_UNROLL
                 for (int n = 0; n < NP; ++n)
-                    D2[rr][n][KHG_SLOT] = D1[rr][n][KHG_SLOT] + KHG_P2 * (S1[rr][n][KHG_SLOT] + X[rr][n][KHG_SLOT]);
+                    KHG_UNROLL
+                    for (int p = 0; p < LP; ++p) {
+                        const double nx = p + 1 < LP ? S1[rr][n][p + 1 < LP ? p + 1 : 0][KHG_SLOT] : X[rr][n][KHG_SLOT];
+                        D2[rr][n][p][KHG_SLOT] = D1[rr][n][p][KHG_SLOT] + KHG_P2 * (S1[rr][n][p][KHG_SLOT] + nx);
+                    }
         }
         // update 2: s2[p] = s1[p] + U2 * (d2[p-1] + d2[p]); scale; columns
         for (int rr = 0; rr < 2; ++rr)
-            for (int n = 0; n < NP; ++n) KHG_LANE_PREV(X[rr][n], D2[rr][n])
+            for (int n = 0; n < NP; ++n) KHG_LANE_PREV(X[rr][n], D2[rr][n][LP - 1])
+        const int k = j - 2;
         KHG_FOR_THREADS(256)
         {
-            const int k = j - 2;
             const bool out = outl[KHG_SLOT] && k >= k0 && k < k1;
             const int pair = pairs[KHG_SLOT];
             const double* rd = &sh.rdiv[KHG_RD_PAD + (pair - P0) + (k - k0)];
-            double rdv[SM::NBAND];
+            double rdv[SM::NBAND][LP];
             KHG_UNROLL
-            for (int s = 0; s < SM::NBAND; ++s) rdv[s] = rd[s * KHG_RD_N];
+            for (int s = 0; s < SM::NBAND; ++s)
+                KHG_UNROLL
+                for (int p = 0; p < LP; ++p) rdv[s][p] = rd[s * SM::RD_N + p];
             KHG_UNROLL
             for (int n = 0; n < NP; ++n) {
-                // row a is the even sample of both columns, row b the odd one
-                double lo[2], hi[2];
+                double s2L[LP], d2L[LP], s2H[LP], d2H[LP];
                 KHG_UNROLL
-                for (int rr = 0; rr < 2; ++rr) {
-                    const double s2 = S1[rr][n][KHG_SLOT] + KHG_U2 * (X[rr][n][KHG_SLOT] + D2[rr][n][KHG_SLOT]);
-                    lo[rr] = khg_fwd_scale_even(s2);
-                    hi[rr] = khg_fwd_scale_odd(D2[rr][n][KHG_SLOT]);
+                for (int p = 0; p < LP; ++p) {
+                    // row a is the even sample of both columns, row b the odd one
+                    double lo[2], hi[2];
+                    KHG_UNROLL
+                    for (int rr = 0; rr < 2; ++rr) {
+                        const double pv = p > 0 ? D2[rr][n][p > 0 ? p - 1 : 0][KHG_SLOT] : X[rr][n][KHG_SLOT];
+                        const double s2 = S1[rr][n][p][KHG_SLOT] + KHG_U2 * (pv + D2[rr][n][p][KHG_SLOT]);
+                        lo[rr] = khg_fwd_scale_even(s2);
+                        hi[rr] = khg_fwd_scale_odd(D2[rr][n][p][KHG_SLOT]);
+                    }
+                    khg_fwd_step(colL[n][p][KHG_SLOT], lo[0], lo[1], s2L[p], d2L[p]);
+                    khg_fwd_step(colH[n][p][KHG_SLOT], hi[0], hi[1], s2H[p], d2H[p]);
                 }
-                double s2L, d2L, s2H, d2H;
-                khg_fwd_step(colL[n][KHG_SLOT], lo[0], lo[1], s2L, d2L);
-                khg_fwd_step(colH[n][KHG_SLOT], hi[0], hi[1], s2H, d2H);
+                double llv[LP];
+                uint32_t words[SM::NBAND];
+                KHG_UNROLL
+                for (int p = 0; p < LP; ++p) llv[p] = 0;
+                KHG_UNROLL
+                for (int s = 0; s < SM::NBAND; ++s) words[s] = 0;
+                bool syms = false;
                 if (out)
-                    khg_col_emit<LEVEL, SM::LHIST>(a, pls[n], sh.cnt[n], sh.first[n], hots[n][KHG_SLOT], pair, k, s2L, d2L,
-                                                   s2H, d2H, rdv, symo[KHG_SLOT], llo[KHG_SLOT]);
+                    syms = khg_col_emit<LEVEL, LP, SM::LHIST>(a, pls[n], sh.cnt[n], sh.first[n], cnts[n][KHG_SLOT],
+                                                              seens[n][KHG_SLOT], dones[KHG_SLOT] != 0, pair, k, s2L, d2L,
+                                                              s2H, d2H, rdv, symo[KHG_SLOT], llv, words);
+                // The trip's stores, outside every condition: the compiler then knows how many stores follow the
+                // loads of the next trip's rows and waits for those loads alone (behind a branch they made it wait
+                // for every store of the trip, once per trip).  Lanes and trips without output store to a dump area
+                // behind the buffer (two pairs per lane: an even pair of an even-pitched buffer, one aligned word /
+                // 16 bytes).
+                if (LEVEL == 1) {
+#ifdef KHG_EXP_NOSTORE  // developer experiment: every store goes to the dump area
+                    const uint32_t o = pls[n].ll_dump + (uint32_t)(8 * LP * tid);
+#else
+                    const uint32_t o = out ? llo[KHG_SLOT] : pls[n].ll_dump + (uint32_t)(8 * LP * tid);
+#endif
+#ifdef KHG_EXP_NTSTORE
+                    for (int p = 0; p < LP; ++p) __builtin_nontemporal_store(llv[p], (double*)((char*)pls[n].ll + o) + p);
+#else
+                    __builtin_memcpy(KHG_ASSUME_ALIGNED((char*)pls[n].ll + o, LP == 2 ? 16 : 8), llv, sizeof llv);
+#endif
+                }
+                KHG_UNROLL
+                for (int s = 0; s < SM::NBAND; ++s) {
+                    const int b4 = s + 4 - SM::NBAND;
+                    const uint32_t boff = b4 == 0 ? 0u : b4 == 1 ? right : b4 == 2 ? down : down + right;
+#ifdef KHG_EXP_NOSTORE
+                    const uint32_t o = pls[n].sym_dump + (uint32_t)(1024 * s + (LP == 2 ? 4 : 2) * tid) + 0 * boff;
+#else
+                    const uint32_t o = syms ? symo[KHG_SLOT] + boff : pls[n].sym_dump + (uint32_t)(1024 * s + (LP == 2 ? 4 : 2) * tid);
+#endif
+                    char* at = (char*)pls[n].sym + o;
+#ifdef KHG_EXP_NTSTORE
+                    if (LP == 2) __builtin_nontemporal_store(words[s], (uint32_t*)at);
+                    else __builtin_nontemporal_store((int16_t)words[s], (int16_t*)at);
+#else
+                    if (LP == 2) __builtin_memcpy(KHG_ASSUME_ALIGNED(at, 4), &words[s], 4);
+                    else *(int16_t*)at = (int16_t)words[s];
+#endif
+                }
             }
             symo[KHG_SLOT] += 2u * (uint32_t)g.sym_pitch;
             llo[KHG_SLOT] += 8u * (uint32_t)g.ll_pitch;
         }
-    }
+        if (k >= k0 && k < k1) {
+            const int t = k - k0 + 1;  // row pairs this segment has emitted
+            if ((t & (KHG_TALLY_TRIPS - 1)) == 0) {
+                KHG_FOR_THREADS(256)
+                {
+                    for (int n = 0; n < NP; ++n) khg_tally_flush<SM::LHIST>(sh.cnt[n], cnts[n][KHG_SLOT]);
+                }
+            }
+            if ((t & (t - 1)) == 0) {  // after 1, 2, 4, ... row pairs: may the wave stop looking for first appearances?
+                KHG_FOR_THREADS(256)
+                {
+                    if (!dones[KHG_SLOT]) {
+                        const int dn = khg_hot_done<NP, SM::LHIST>(sh.first, (uint32_t)(k + 1) * (uint32_t)g.sym_pitch);
+                        dones[KHG_SLOT] = KHG_UNIFORM(dn);
+                    }
+                }
+            }
+        }
+    };
+#if !defined(KHG_SIM) && defined(KHG_FWD_UNROLL2)
+    if (!idle)
+        for (int j = k0 - 2; j <= jend; j += 2) {
+            trip(j);
+            trip(j + 1);
+        }
+#else
+    if (!idle)
+        for (int j = k0 - 2; j <= jend; ++j) trip(j);
+#endif
 
     KHG_FOR_THREADS(256)
     {
-        for (int n = 0; n < NP; ++n) {
-            const KhgHot hot = hots[n][KHG_SLOT];
-            for (int v = 0; v < 3; ++v) {  // byte v counts symbol 1 - v
-                uint32_t c = (hot >> (8 * v)) & 0xFFu;
-                if (c) khg_lds_add(&sh.cnt[n][SM::LHIST_BIAS + 1 - v], c);
-            }
-        }
+        for (int n = 0; n < NP; ++n) khg_tally_flush<SM::LHIST>(sh.cnt[n], cnts[n][KHG_SLOT]);
     }
     KHG_BARRIER();
     KHG_FOR_THREADS(256)
@@ -673,32 +946,40 @@ KHG_DEV void khg_fwd_wg_body(const KhgFwdArgs& a, const KhgFwdPlane* pls, int wg
 enum { KHG_FWD_RGB = 0, KHG_FWD_PLANES1 = 1, KHG_FWD_PLANES2 = 2, KHG_FWD_BGR = 3 };
 
 #if defined(KHG_TIMING) && !defined(KHG_SIM)
-// developer build: per-workgroup start / end stamps (100 MHz) and hardware id of the last forward launch
-__device__ uint32_t khg_dbg_fwd[4 * 8192];
+// developer build: per-workgroup start / end stamps (100 MHz), hardware id and shader-clock cycles of the last forward launch
+__device__ uint32_t khg_dbg_fwd[8 * 8192];
 #define KHG_FWD_STAMP(wg, slot, v) \
-    if (threadIdx.x == 0 && (wg) < 8192) khg_dbg_fwd[4 * (wg) + (slot)] = (v)
+    if (threadIdx.x == 0 && (wg) < 8192) khg_dbg_fwd[8 * (wg) + (slot)] = (v)
 #else
 #define KHG_FWD_STAMP(wg, slot, v)
 #endif
 
 // Workgroup `wg` of a launch: which plane it belongs to, and its body.
-template <int KIND>
+template <int KIND, int LP, int LPC>
 KHG_DEV void khg_fwd_launch_body(const KhgFwdArgs& a, int wg, KhgFwdSmemAny& sh)
 {
+#ifndef KHG_EXP_NOREMAP
+    wg = khg_xcd_remap(wg, a.nwg);
+#endif
     KHG_FWD_STAMP(wg, 0, (uint32_t)wall_clock64());
     KHG_FWD_STAMP(wg, 2, __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)));  // HW_ID
     KHG_FWD_STAMP(wg, 3, __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)));  // XCC_ID
+    KHG_FWD_STAMP(wg, 4, (uint32_t)__builtin_amdgcn_s_memtime());
     if constexpr (KIND == KHG_FWD_RGB) {
-        if (a.nplanes < 2 || wg < a.pl[1].wg0) khg_fwd_wg_body<KHG_SRC_Y, 1, 1>(a, &a.pl[0], wg, sh.y);
-        else khg_fwd_wg_body<KHG_SRC_C, 1, 2>(a, &a.pl[1], wg - a.pl[1].wg0, sh.c);
+        if (a.nplanes < 2 || wg < a.pl[1].wg0)
+            khg_fwd_wg_body<KHG_SRC_Y, 1, 1, LP>(a, &a.pl[0], wg, *(KhgFwdSmem<1, 1, LP>*)&sh);
+        else khg_fwd_wg_body<KHG_SRC_C, 1, 2, LPC>(a, &a.pl[1], wg - a.pl[1].wg0, *(KhgFwdSmem<1, 2, LPC>*)&sh);
     } else if constexpr (KIND == KHG_FWD_BGR) {
-        if (a.nplanes < 2 || wg < a.pl[1].wg0) khg_fwd_wg_body<KHG_SRC_Y_BGR, 1, 1>(a, &a.pl[0], wg, sh.y);
-        else khg_fwd_wg_body<KHG_SRC_C_BGR, 1, 2>(a, &a.pl[1], wg - a.pl[1].wg0, sh.c);
+        if (a.nplanes < 2 || wg < a.pl[1].wg0)
+            khg_fwd_wg_body<KHG_SRC_Y_BGR, 1, 1, LP>(a, &a.pl[0], wg, *(KhgFwdSmem<1, 1, LP>*)&sh);
+        else khg_fwd_wg_body<KHG_SRC_C_BGR, 1, 2, LPC>(a, &a.pl[1], wg - a.pl[1].wg0, *(KhgFwdSmem<1, 2, LPC>*)&sh);
     } else {
         int p = 0;
         while (p + 1 < a.nplanes && wg >= a.pl[p + 1].wg0) ++p;
-        if constexpr (KIND == KHG_FWD_PLANES1) khg_fwd_wg_body<KHG_SRC_PLANE, 1, 1>(a, &a.pl[p], wg - a.pl[p].wg0, sh.y);
-        else khg_fwd_wg_body<KHG_SRC_PLANE, 2, 1>(a, &a.pl[p], wg - a.pl[p].wg0, sh.l2);
+        if constexpr (KIND == KHG_FWD_PLANES1)
+            khg_fwd_wg_body<KHG_SRC_PLANE, 1, 1, LP>(a, &a.pl[p], wg - a.pl[p].wg0, *(KhgFwdSmem<1, 1, LP>*)&sh);
+        else khg_fwd_wg_body<KHG_SRC_PLANE, 2, 1, LP>(a, &a.pl[p], wg - a.pl[p].wg0, *(KhgFwdSmem<2, 1, LP>*)&sh);
     }
     KHG_FWD_STAMP(wg, 1, (uint32_t)wall_clock64());
+    KHG_FWD_STAMP(wg, 5, (uint32_t)__builtin_amdgcn_s_memtime());
 }

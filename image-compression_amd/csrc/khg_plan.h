@@ -87,10 +87,10 @@ struct KhgWorkspaceSizes {
 static inline void khg_workspace_sizes(int rows, int cols, KhgWorkspaceSizes* s)
 {
     size_t ny = (size_t)rows * cols, nc = ny / 4;
-    s->ll[0] = nc * sizeof(double);
-    s->ll[1] = s->ll[2] = (nc / 4) * sizeof(double);
-    s->sym[0] = ny * sizeof(int16_t);
-    s->sym[1] = s->sym[2] = nc * sizeof(int16_t);
+    s->ll[0] = nc * sizeof(double) + KHG_DUMP_BYTES;
+    s->ll[1] = s->ll[2] = (nc / 4) * sizeof(double) + KHG_DUMP_BYTES;
+    s->sym[0] = ny * sizeof(int16_t) + KHG_DUMP_BYTES;
+    s->sym[1] = s->sym[2] = nc * sizeof(int16_t) + KHG_DUMP_BYTES;
     s->hist = 3 * (size_t)KHG_NBINS * sizeof(uint32_t);
     s->tab = 3 * (size_t)KHG_NBINS * sizeof(int32_t);
     s->codetab = 3 * (size_t)KHG_NBINS * sizeof(uint64_t);
@@ -154,6 +154,8 @@ static inline void khg_fwd_plane(KhgFwdPlane* pl, const KhgWorkspace& ws, int ro
     pl->ll_pitch = pcol / 2;
     pl->sym = ws.sym[comp];
     pl->sym_pitch = pcol;
+    pl->sym_dump = (uint32_t)((size_t)prow * pcol * sizeof(int16_t));
+    pl->ll_dump = (uint32_t)((size_t)(prow / 2) * (pcol / 2) * sizeof(double));
     pl->coef = coef;
     pl->coef_pitch = pcol;
     pl->hist_cnt = ws.hist_cnt + (size_t)comp * KHG_NBINS;
@@ -173,9 +175,13 @@ static inline void khg_fwd_plane(KhgFwdPlane* pl, const KhgWorkspace& ws, int ro
     }
 }
 
-// Workgroups of the chip that a transform launch is planned for: 4 per CU (4 waves per SIMD) on 256 CUs.
+// Workgroups of the chip that a transform launch is planned for: 4 per CU (4 waves per SIMD) on 256 CUs, for the
+// kernels with one and with two sample pairs per lane alike (both are compiled for at most 128 registers).
 #ifndef KHG_FWD_SLOTS
 #define KHG_FWD_SLOTS 1024
+#endif
+#ifndef KHG_FWD_SLOTS_LP2
+#define KHG_FWD_SLOTS_LP2 1024
 #endif
 
 // One group of planes of a transform launch that share a grid (Y alone, Cb with Cr, ...): pw columns, `span` rows
@@ -183,6 +189,7 @@ static inline void khg_fwd_plane(KhgFwdPlane* pl, const KhgWorkspace& ws, int ro
 // planner fills in the rest.
 struct KhgGridGroup {
     int pw, span, weight;
+    int strip_pairs;  // output pairs of one wave's strip
     int seg_rows, nseg, nstrip_wg, wg0;
 };
 
@@ -196,7 +203,7 @@ enum { KHG_SEG_WARMUP = 8 };  // rows a workgroup transforms before its segment'
 static inline int khg_plan_groups(KhgGridGroup* g, int ngroup, int slots)
 {
     for (int i = 0; i < ngroup; ++i) {
-        const int nstrips = (g[i].pw / 2 + KHG_STRIP_PAIRS - 1) / KHG_STRIP_PAIRS;
+        const int nstrips = (g[i].pw / 2 + g[i].strip_pairs - 1) / g[i].strip_pairs;
         g[i].nstrip_wg = (nstrips + KHG_WG_STRIPS - 1) / KHG_WG_STRIPS;
     }
     for (long T = 1;; ++T) {  // cost per workgroup
@@ -231,8 +238,9 @@ static inline void khg_fwd_plan_grid(KhgFwdArgs* a, int ngroup, const int* first
     for (int i = 0; i < ngroup; ++i) {
         const KhgFwdPlane& pl = a->pl[first[i]];
         g[i].pw = pl.pw; g[i].span = pl.row_end - pl.row_begin; g[i].weight = weight[i];
+        g[i].strip_pairs = KHG_STRIP_PAIRS_LP(count[i] == 2 ? a->lpc : a->lp);
     }
-    a->nwg = khg_plan_groups(g, ngroup, KHG_FWD_SLOTS);
+    a->nwg = khg_plan_groups(g, ngroup, a->lp == 2 ? KHG_FWD_SLOTS_LP2 : KHG_FWD_SLOTS);
     for (int i = 0; i < ngroup; ++i)
         for (int j = 0; j < count[i]; ++j) {
             KhgFwdPlane& o = a->pl[first[i] + j];
@@ -265,6 +273,8 @@ static inline KhgFwdArgs khg_fwd_args_rgb(const KhgWorkspace& ws, const uint8_t*
     // a row of a chroma workgroup (Cb and Cr together, half the strips' pixels each) costs 2.25 luma rows (measured)
     const int first[2] = {0, 1}, count[2] = {1, 2}, weight[2] = {4, 9};
     a.nplanes = luma_only ? 1 : 3;
+    a.lp = khg_fwd_lp_for(a);
+    a.lpc = a.lp == 2 ? KHG_FWD_LPC : 1;
     a.lhist = 256;
     khg_fwd_plan_grid(&a, luma_only ? 1 : 2, first, count, weight);
     return a;
@@ -282,6 +292,7 @@ static inline KhgFwdArgs khg_fwd_args_planes(const KhgWorkspace& ws, int rows, i
         khg_fwd_plane(&a.pl[p], ws, rows, cols, lvl, p, level, coef ? coef[p] : nullptr, tile, ycbcr ? ycbcr[p] : nullptr);
     const int first[3] = {0, 1, 2}, count[3] = {1, 1, 1}, weight[3] = {1, 1, 1};
     a.nplanes = 3;
+    a.lp = a.lpc = khg_fwd_lp_for(a);
     a.lhist = level == 1 ? 256 : (lvl == 0 ? 2048 : 1024);  // Normal preset: luma LL symbols reach 1009 (255 * 4 / 1.011)
     khg_fwd_plan_grid(&a, 3, first, count, weight);
     return a;

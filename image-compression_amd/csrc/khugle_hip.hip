@@ -19,11 +19,16 @@
 
 // KIND: KHG_FWD_RGB (level 1 of Y, Cb, Cr from u8 RGB), KHG_FWD_PLANES1 (level 1 from f64 planes),
 // KHG_FWD_PLANES2 (level 2 of the three components).
-template <int KIND>
-__global__ __launch_bounds__(256) void khg_fwd_kernel(KhgFwdArgs a)
+// LP: sample pairs per lane; with two the kernel is planned for two workgroups per CU (up to 256 registers).
+// LPC: the same for the workgroups that carry Cb and Cr.
+#ifndef KHG_FWD_LP2_WAVES
+#define KHG_FWD_LP2_WAVES 4  // workgroups per CU (waves per SIMD) the two-pair kernels are compiled for; see KHG_FWD_SLOTS_LP2
+#endif
+template <int KIND, int LP, int LPC>
+__global__ __launch_bounds__(256, LP == 2 ? KHG_FWD_LP2_WAVES : 4) void khg_fwd_kernel(KhgFwdArgs a)
 {
     __shared__ KhgFwdSmemAny sh;
-    khg_fwd_launch_body<KIND>(a, (int)blockIdx.x, sh);
+    khg_fwd_launch_body<KIND, LP, LPC>(a, (int)blockIdx.x, sh);
 }
 
 __global__ __launch_bounds__(256) void khg_table_kernel(KhgTableArgs a)
@@ -451,7 +456,8 @@ static int khg_end(khg_ctx* c, hipStream_t st, int pending)
 template <int KIND>
 static void khg_launch_fwd(const KhgFwdArgs& a, hipStream_t st)
 {
-    hipLaunchKernelGGL((khg_fwd_kernel<KIND>), dim3(a.nwg), dim3(256), 0, st, a);
+    if (a.lp == 2) hipLaunchKernelGGL((khg_fwd_kernel<KIND, 2, KHG_FWD_LPC>), dim3(a.nwg), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((khg_fwd_kernel<KIND, 1, 1>), dim3(a.nwg), dim3(256), 0, st, a);
 }
 
 // Colour + both DWT levels + quantiser + histograms for the three components.

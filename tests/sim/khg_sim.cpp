@@ -55,7 +55,10 @@ struct SimWs {
 template <int KIND>
 void run_fwd(const KhgFwdArgs& a) {
     KhgFwdSmemAny* sh = new KhgFwdSmemAny;
-    for (int wg = 0; wg < a.nwg; ++wg) khg_fwd_launch_body<KIND>(a, wg, *sh);
+    for (int wg = 0; wg < a.nwg; ++wg) {
+        if (a.lp == 2) khg_fwd_launch_body<KIND, 2, KHG_FWD_LPC>(a, wg, *sh);
+        else khg_fwd_launch_body<KIND, 1, 1>(a, wg, *sh);
+    }
     delete sh;
 }
 
@@ -678,7 +681,7 @@ void khgsim_synth(uint8_t* r, uint8_t* g, uint8_t* b, int rows, int cols, uint32
 int khgsim_plan_groups(const int* groups, int ngroup, int slots, int* out)
 {
     KhgGridGroup g[3];
-    for (int i = 0; i < ngroup; ++i) { g[i].pw = groups[3 * i]; g[i].span = groups[3 * i + 1]; g[i].weight = groups[3 * i + 2]; }
+    for (int i = 0; i < ngroup; ++i) { g[i].pw = groups[3 * i]; g[i].span = groups[3 * i + 1]; g[i].weight = groups[3 * i + 2]; g[i].strip_pairs = KHG_STRIP_PAIRS; }
     const int n = khg_plan_groups(g, ngroup, slots);
     for (int i = 0; i < ngroup; ++i) { out[4 * i] = g[i].seg_rows; out[4 * i + 1] = g[i].nseg; out[4 * i + 2] = g[i].nstrip_wg; out[4 * i + 3] = g[i].wg0; }
     return n;
@@ -697,7 +700,8 @@ void khgsim_round_quot(const double* x, const double* d, size_t n, double* out_r
 {
     for (size_t i = 0; i < n; ++i) {
         int q;
-        const bool ok = khg_quant_try(x[i], 1.0 / d[i], &q);  // the kernels' shortcut; they divide when it declines
+        uint32_t nhi;
+        const bool ok = khg_quant_try(x[i], 1.0 / d[i], &q, &nhi);  // the kernels' shortcut; they divide when it declines
         out_round[i] = ok ? (double)q : round(x[i] / d[i]);
         fast[i] = ok;
     }

@@ -13,6 +13,6 @@ from khugle_amd import Codec
 H, W = 4320, 7680
 c = Codec(H, W)
 f = c.synth_dev(H, W, 2025, 0)
-for _ in range(2):
-    ms = c.time_luma_forward_dev(f, 1, reps=20)
-print("level-1 forward launch: %.1f us" % (ms * 1e3))
+c.time_luma_forward_dev(f, 1, reps=20)
+ts = sorted(c.time_luma_forward_dev(f, 1, reps=20) * 1e3 for _ in range(int(os.environ.get("KHG_ROUNDS", "7"))))
+print("level-1 forward launch: min %.1f median %.1f max %.1f us" % (ts[0], ts[len(ts) // 2], ts[-1]))

@@ -18,13 +18,17 @@ for _ in range(2):
     ms = c.time_luma_forward_dev(f, 1, reps=5)
 print("level-1 forward launch: %.1f us" % (ms * 1e3))
 lib = C.CDLL(khugle_amd.lib.LIB_PATH)
-buf = np.zeros(4 * 8192, dtype=np.uint32)
+buf = np.zeros(8 * 8192, dtype=np.uint32)
 lib.khg_debug_fwd.argtypes = [C.c_void_p, C.c_size_t]
 assert lib.khg_debug_fwd(buf.ctypes.data, buf.size) == 0
-w = buf.reshape(-1, 4)
+w = buf.reshape(-1, 8)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 nl = int(sys.argv[2]) if len(sys.argv) > 2 else 688
 w = w[:n]
+if os.environ.get("KHG_REMAP", "1") == "1":  # stamps are stored by hardware workgroup id; classify by the work index
+    q, r = divmod(n, 8)
+    work = np.array([(x % 8) * (q + 1) + x // 8 if x % 8 < r else r * (q + 1) + (x % 8 - r) * q + x // 8 for x in range(n)])
+    w = w[np.argsort(work)]
 t0 = w[:, 0].min()
 st = (w[:, 0] - t0).astype(np.int64) / 100.0  # us
 en = (w[:, 1] - t0).astype(np.int64) / 100.0
@@ -48,3 +52,6 @@ for i in range(n):
 for k in list(mix)[:12]:
     print(k, mix[k])
 print("span of the launch %.1f us" % (en.max() - st.min()))
+cyc = (w[:, 5].astype(np.int64) - w[:, 4].astype(np.int64)) & 0xFFFFFFFF
+ghz = cyc / np.maximum(du, 1e-3) / 1e3
+print("shader clock held inside the workgroups: median %.2f GHz (min %.2f, max %.2f)" % (np.median(ghz), ghz.min(), ghz.max()))

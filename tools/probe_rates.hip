@@ -6,12 +6,14 @@
 #include <cstdio>
 #include <cstdint>
 #include <vector>
+#include <algorithm>
 
 #define REP8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
 
 template <int OP>
-__global__ __launch_bounds__(256) void rate_kernel(double* out, int iters, uint32_t seed)
+__global__ __launch_bounds__(256) void rate_kernel(double* out, int iters, uint32_t seed, unsigned long long* clk)
 {
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     double d[8];
     uint32_t u[8];
     float f[8];
@@ -42,7 +44,16 @@ __global__ __launch_bounds__(256) void rate_kernel(double* out, int iters, uint3
     if (OP == 16) asm volatile("v_rndne_f64 %0, %0" : "+v"(d[i]));                                      \
     if (OP == 17) asm volatile("v_mul_lo_u32 %0, %0, %0" : "+v"(u[i]));                                 \
     if (OP == 18) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(d[i]) : "v"(c));                        \
-    if (OP == 19) asm volatile("v_add_f64 %0, -|%0|, 0.5" : "+v"(d[i]));
+    if (OP == 19) asm volatile("v_add_f64 %0, -|%0|, 0.5" : "+v"(d[i]));                                \
+    if (OP == 20) asm volatile("v_mov_b32_dpp %0, %0 wave_shl:1 row_mask:0xf bank_mask:0xf" : "+v"(u[i])); \
+    if (OP == 21) asm volatile("v_or3_b32 %0, %0, %1, %1" : "+v"(u[i]) : "v"(u[(i + 1) & 7]));          \
+    if (OP == 22) asm volatile("v_max3_u32 %0, %0, %1, %1" : "+v"(u[i]) : "v"(u[(i + 1) & 7]));         \
+    if (OP == 23) asm volatile("v_alignbyte_b32 %0, %0, %1, %1" : "+v"(u[i]) : "v"(u[(i + 1) & 7]));    \
+    if (OP == 24) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(u[i]) : "v"(u[(i + 1) & 7]) : "vcc"); \
+    if (OP == 25) asm volatile("v_mad_i32_i24 %0, %0, %0, %1" : "+v"(u[i]) : "v"(u[(i + 1) & 7]));      \
+    if (OP == 26) asm volatile("v_cvt_f32_ubyte1 %0, %1" : "=v"(f[i]) : "v"(u[i]));                     \
+    if (OP == 27) asm volatile("v_max_f64 %0, |%0|, |%1|" : "+v"(d[i]) : "v"(c));                       \
+    if (OP == 28) asm volatile("v_lshl_or_b32 %0, %0, 3, %1" : "+v"(u[i]) : "v"(u[(i + 1) & 7]));
         REP8(ONE)
         REP8(ONE)
 #undef ONE
@@ -50,24 +61,34 @@ __global__ __launch_bounds__(256) void rate_kernel(double* out, int iters, uint3
     double s = 0;
     for (int i = 0; i < 8; ++i) s += d[i] + u[i] + f[i];
     out[blockIdx.x * 256 + threadIdx.x] = s;
+    // shader cycles and 100 MHz ticks this workgroup lived: their ratio is the clock the chip held under this load
+    if (threadIdx.x == 0 && clk) {
+        clk[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - t0;
+        clk[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - r0;
+    }
 }
 
 static const char* names[] = {"v_add_f64", "v_mul_f64", "v_fma_f64", "v_cvt_f64_u32", "v_trunc_f64", "v_ldexp_f64",
                               "v_cvt_i32_f64", "v_cvt_f32_ubyte1", "v_cvt_f64_f32", "v_bfe_u32", "v_cmp_gt_f64",
                               "v_lshlrev_b64", "v_lshl_add_u64", "v_mov_b64", "v_add_u32", "v_cvt_f64_i32",
-                              "v_rndne_f64", "v_mul_lo_u32", "v_pk_add_f32", "v_add_f64 mods"};
+                              "v_rndne_f64", "v_mul_lo_u32", "v_pk_add_f32", "v_add_f64 mods", "v_mov_b32_dpp",
+                              "v_or3_b32", "v_max3_u32", "v_alignbyte_b32", "v_cndmask_b32", "v_mad_i32_i24",
+                              "v_cvt_f32_ubyte1 b", "v_max_f64 abs", "v_lshl_or_b32"};
 
 template <int OP>
 static void run(double* out, int blocks, double ghz)
 {
     const int iters = 4096;
+    static unsigned long long* clk = nullptr;
+    if (!clk) hipMalloc(&clk, sizeof(unsigned long long) * 2 * blocks);
     hipEvent_t a, b;
     hipEventCreate(&a);
     hipEventCreate(&b);
-    rate_kernel<OP><<<blocks, 256>>>(out, 64, 1);
+    rate_kernel<OP><<<blocks, 256>>>(out, 64, 1, nullptr);
+    for (int w = 0; w < 40; ++w) rate_kernel<OP><<<blocks, 256>>>(out, iters, 1, nullptr);  // let the clock settle under this load
     hipDeviceSynchronize();
     hipEventRecord(a);
-    rate_kernel<OP><<<blocks, 256>>>(out, iters, 1);
+    rate_kernel<OP><<<blocks, 256>>>(out, iters, 1, clk);
     hipEventRecord(b);
     hipEventSynchronize(b);
     float ms = 0;
@@ -75,9 +96,15 @@ static void run(double* out, int blocks, double ghz)
     // waves per SIMD = blocks * 4 waves / (256 CUs * 4 SIMDs); every SIMD issues waves_per_simd * iters * 16 instr
     double waves_per_simd = blocks * 4.0 / 1024.0;
     double instr = waves_per_simd * iters * 16.0;
-    double cycles = ms * 1e-3 * ghz * 1e9;
-    printf("%-20s %8.3f ms  %6.2f cycles per wave64 instruction (at %.2f GHz, %g waves/SIMD)\n", names[OP], ms,
-           cycles / instr, ghz, waves_per_simd);
+    std::vector<unsigned long long> h(2 * blocks);
+    hipMemcpy(h.data(), clk, sizeof(unsigned long long) * 2 * blocks, hipMemcpyDeviceToHost);
+    std::vector<double> g;
+    for (int i = 0; i < blocks; ++i) g.push_back((double)h[2 * i] / (double)h[2 * i + 1] * 0.1);  // GHz in this workgroup
+    std::sort(g.begin(), g.end());
+    const double held = g[g.size() / 2];
+    printf("%-20s %8.3f ms  %5.2f ns per wave64 instruction and SIMD = %5.2f cycles at the %.2f GHz held in the kernel "
+           "(nominal %.2f GHz, %g waves/SIMD)\n", names[OP], ms, ms * 1e6 / instr, ms * 1e-3 * held * 1e9 / instr, held, ghz,
+           waves_per_simd);
     hipEventDestroy(a);
     hipEventDestroy(b);
 }
@@ -110,6 +137,15 @@ int main()
     run<17>(out, blocks, ghz);
     run<18>(out, blocks, ghz);
     run<19>(out, blocks, ghz);
+    run<20>(out, blocks, ghz);
+    run<21>(out, blocks, ghz);
+    run<22>(out, blocks, ghz);
+    run<23>(out, blocks, ghz);
+    run<24>(out, blocks, ghz);
+    run<25>(out, blocks, ghz);
+    run<26>(out, blocks, ghz);
+    run<27>(out, blocks, ghz);
+    run<28>(out, blocks, ghz);
     hipFree(out);
     return 0;
 }
