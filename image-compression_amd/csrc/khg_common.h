@@ -20,6 +20,7 @@
 #define KHG_SLOT tid
 #define KHG_BARRIER() ((void)0)
 #define KHG_OPAQUE(x) ((void)0)
+#define KHG_KEEP_SCALAR(x) ((void)0)
 #define KHG_TOUCH(reg, ptr) ((void)(reg), (void)(ptr))
 #define KHG_TOUCH_DONE(reg) ((void)(reg))
 #define KHG_UNROLL
@@ -97,6 +98,10 @@ static inline void khg_chain_store(uint64_t* p, uint64_t v) { *p = v; }
 // Makes a 32-bit value opaque to the optimiser at this point: what is computed from it afterwards cannot be hoisted
 // out of the (rarely taken) path it sits on into the common path, where it would only cost registers.
 #define KHG_OPAQUE(x) asm volatile("" : "+v"(x))
+// Pins a wave-uniform 32-bit value read from the kernel's argument block to a scalar register: the compiler can then
+// no longer fetch it from the argument block again wherever it is used (inside a loop that is a load and a wait per
+// trip); under register pressure it parks it in a lane of a vector register instead.
+#define KHG_KEEP_SCALAR(x) asm volatile("" : "+s"(x))
 // Cache warming: a 4-byte load whose result nobody waits for (gfx9 has no prefetch instruction).  `reg` is a 32-bit
 // variable that lives from before the first KHG_TOUCH to KHG_TOUCH_DONE, so the register the data eventually lands
 // in is never handed to anything else; KHG_TOUCH_DONE drains the memory counter before the variable dies.

@@ -83,6 +83,7 @@ struct KhgFwdArgs {
     int lp;                    // sample pairs per lane (1 or 2) of the luma / plane workgroups: which instantiation
                                // of the kernel the grid is planned for
     int lpc;                   // the same for the workgroups that carry Cb and Cr (RGB launches)
+    int tap;                   // some plane has a coefficient tap (KhgFwdPlane::coef): the instantiation that stores them
     // RGB launch: [0] = Y, [1] = Cb, [2] = Cr (Cb and Cr share one grid: a lane carries both).
     // Plane launches: up to three independent planes.
     KhgFwdPlane pl[3];
@@ -237,27 +238,48 @@ KHG_DEV uint32_t khg_fwd_row_offset(const KhgFwdArgs& a, const KhgFwdPlane& pl, 
     return (uint32_t)r * (uint32_t)a.img_w;
 }
 
+// What khg_fwd_row_offsets needs of the launch, read once before the loop (left in the argument block the values
+// were fetched from it again on every trip, each fetch a wait).
+struct KhgFwdRows {
+    int ph, pitch, in_row0, in_rows;  // pitch: elements per row of the source (BGR: bytes)
+};
+template <int SRC>
+KHG_DEV KhgFwdRows khg_fwd_rows(const KhgFwdArgs& a, const KhgFwdPlane& pl)
+{
+    KhgFwdRows r;
+    r.ph = KHG_UNIFORM(pl.ph);
+    r.pitch = KHG_UNIFORM(SRC == KHG_SRC_PLANE ? pl.src_pitch : KHG_SRC_IS_BGR(SRC) ? a.bgr_stride : a.img_w);
+    r.in_row0 = KHG_UNIFORM(a.in_row0);
+    r.in_rows = KHG_UNIFORM(a.in_rows);
+    KHG_KEEP_SCALAR(r.ph);
+    KHG_KEEP_SCALAR(r.pitch);
+    KHG_KEEP_SCALAR(r.in_row0);
+    KHG_KEEP_SCALAR(r.in_rows);
+    return r;
+}
+
 // Offsets of the two source rows of row pair j (plane rows 2j and 2j+1, reflected into the plane).  Nearly every
 // trip's rows are plain rows of the plane and of the r/g/b band: that case is a few scalar instructions.
 template <int SRC>
-KHG_DEV void khg_fwd_row_offsets(const KhgFwdArgs& a, const KhgFwdPlane& pl, int j, uint32_t& oa, uint32_t& ob)
+KHG_DEV void khg_fwd_row_offsets(const KhgFwdArgs& a, const KhgFwdPlane& pl, const KhgFwdRows& rw, int j, uint32_t& oa,
+                                 uint32_t& ob)
 {
-    const int ya = 2 * j, ph = KHG_UNIFORM(pl.ph);
+    const int ya = 2 * j, ph = rw.ph;
     if (ya >= 0 && ya + 1 < ph) {
         if (SRC == KHG_SRC_PLANE) {
-            oa = (uint32_t)ya * (uint32_t)KHG_UNIFORM(pl.src_pitch);
-            ob = oa + (uint32_t)KHG_UNIFORM(pl.src_pitch);
+            oa = (uint32_t)ya * (uint32_t)rw.pitch;
+            ob = oa + (uint32_t)rw.pitch;
             return;
         }
         const int f = KHG_SRC_IS_LUMA(SRC) ? 1 : 2;
-        const int ra = f * ya - KHG_UNIFORM(a.in_row0), rb = ra + f;
-        if (ra >= 0 && rb < KHG_UNIFORM(a.in_rows)) {
+        const int ra = f * ya - rw.in_row0, rb = ra + f;
+        if (ra >= 0 && rb < rw.in_rows) {
             if (KHG_SRC_IS_BGR(SRC)) {
-                oa = (uint32_t)(KHG_UNIFORM(a.in_rows) - 1 - ra) * (uint32_t)KHG_UNIFORM(a.bgr_stride);
-                ob = (uint32_t)(KHG_UNIFORM(a.in_rows) - 1 - rb) * (uint32_t)KHG_UNIFORM(a.bgr_stride);
+                oa = (uint32_t)(rw.in_rows - 1 - ra) * (uint32_t)rw.pitch;
+                ob = (uint32_t)(rw.in_rows - 1 - rb) * (uint32_t)rw.pitch;
             } else {
-                oa = (uint32_t)ra * (uint32_t)KHG_UNIFORM(a.img_w);
-                ob = (uint32_t)rb * (uint32_t)KHG_UNIFORM(a.img_w);
+                oa = (uint32_t)ra * (uint32_t)rw.pitch;
+                ob = (uint32_t)rb * (uint32_t)rw.pitch;
             }
             return;
         }
@@ -515,17 +537,18 @@ KHG_DEV void khg_tally_flush(uint32_t* lcnt, uint32_t& cnt)
 // Finished, unscaled outputs (s2, d2) of row pair k of the low-half column (L) and high-half column (H) of the
 // lane's LP pairs (the first is pair `pair`): scale, store / quantise, count.  rd[s][p]: reciprocal divisors per band
 // slot and pair (khg_fwd_rdiv_entry); so, llo: byte offsets of position (k, pair) in the symbol plane and in the LL
-// buffer; done: nothing this wave emits from here on can lower the first-appearance index of -1, 0 or +1.
+// buffer; done: nothing this wave emits from here on can lower the first-appearance index of -1, 0 or +1; emit: the
+// row pair's symbols are stored and counted (KhgFwdPlane::emit_k0, emit_k1); hh, hw: half the plane's rows and
+// columns; right, down: byte offsets in the symbol plane from (k, pair) to (k, hw + pair) and to (hh + k, pair).
 // Nothing is stored here: llv receives the level-1 LL values, words the symbols of each band slot (two pairs per
 // lane: both in one word), and the result says whether the symbols are to be stored (see the caller).
-template <int LEVEL, int LP, int LHIST>
+template <int LEVEL, int LP, int LHIST, bool TAP>
 KHG_DEV bool khg_col_emit(const KhgFwdArgs& a, const KhgFwdPlane& pl, uint32_t* lcnt, uint32_t* lfirst, uint32_t& cnt,
-                          uint32_t& seen, bool done, int pair, int k, const double* s2L, const double* d2L,
-                          const double* s2H, const double* d2H, const double (*rd)[LP], uint32_t so, double* llv,
-                          uint32_t* words)
+                          uint32_t& seen, bool done, bool emit, int hh, int hw, uint32_t right, uint32_t down, int pair,
+                          int k, const double* s2L, const double* d2L, const double* s2H, const double* d2H,
+                          const double (*rd)[LP], uint32_t so, double* llv, uint32_t* words)
 {
-    const int hh = pl.ph / 2, hw = pl.pw / 2;
-    if (pl.coef) {
+    if (TAP && pl.coef) {
         KHG_UNROLL
         for (int p = 0; p < LP; ++p) {
             const uint32_t c0 = (uint32_t)k * (uint32_t)pl.coef_pitch + (uint32_t)(pair + p);
@@ -540,11 +563,10 @@ KHG_DEV bool khg_col_emit(const KhgFwdArgs& a, const KhgFwdPlane& pl, uint32_t* 
         KHG_UNROLL
         for (int p = 0; p < LP; ++p) llv[p] = khg_fwd_scale_even(s2L[p]);
     }
-    if (!(k >= pl.emit_k0 && k < pl.emit_k1)) return false;
+    if (!emit) return false;  // a row pair a tile transforms for its neighbour's LL values only
     // Bands of this level (Compress.h:154-160): LL (level 2 only: band 0), then the three detail bands -- high-half
     // column of low-pass row k, low-half and high-half column of high-pass row hh + k.
     enum { NB = LEVEL == 1 ? 3 : 4, B0 = LEVEL == 1 ? 4 : 0, D0 = LEVEL == 1 ? 0 : 1, NS = NB * LP };
-    const uint32_t right = 2u * (uint32_t)hw, down = 2u * (uint32_t)hh * (uint32_t)pl.sym_pitch;
     const uint32_t boff[4] = {0, right, down, down + right};  // of slot s: boff[s + 4 - NB]
     int q[NB][LP];
     uint32_t nhi[NB][LP];
@@ -583,12 +605,18 @@ KHG_DEV bool khg_col_emit(const KhgFwdArgs& a, const KhgFwdPlane& pl, uint32_t* 
                 v = 0;  // stored and counted as a zero; the job fails with KHG_ERR_RANGE
             }
             const uint32_t raster = (so + 2u * (uint32_t)p) >> 1;
+#ifdef KHG_EXP_NOLLHIST
+            if (v == 12345) {
+#else
             if ((unsigned)(v + a.lhist / 2) < (unsigned)a.lhist) {
+#endif
                 khg_lds_add(&lcnt[v + LHIST / 2], 1u);
                 khg_lds_min(&lfirst[v + LHIST / 2], raster);
             } else {
+#ifndef KHG_EXP_NOLLHIST
                 khg_atomic_add(&pl.hist_cnt[v + KHG_SYM_BIAS], 1u);
                 khg_atomic_min(&pl.hist_first[v + KHG_SYM_BIAS], raster);
+#endif
             }
             q[0][p] = v;
         }
@@ -635,9 +663,22 @@ KHG_DEV bool khg_hot_done(uint32_t (*lfirst)[LHIST], uint32_t before)
     return all;
 }
 
+#if defined(KHG_TIMING) && !defined(KHG_SIM)
+// developer build: per-workgroup start / end stamps (100 MHz), hardware id and shader-clock cycles of the last forward launch
+__device__ uint32_t khg_dbg_fwd[8 * 8192];
+#define KHG_FWD_STAMP(wg, slot, v) \
+    if (threadIdx.x == 0 && (wg) < 8192) khg_dbg_fwd[8 * (wg) + (slot)] = (v)
+#define KHG_FWD_STAMP_HERE(slot) KHG_FWD_STAMP(khg_xcd_remap((int)blockIdx.x, a.nwg), slot, (uint32_t)wall_clock64())
+#else
+#define KHG_FWD_STAMP(wg, slot, v)
+#define KHG_FWD_STAMP_HERE(slot)
+#endif
+
 // One workgroup: KHG_WG_STRIPS adjacent strips (one per wave) over one segment of rows of NP planes of equal
 // geometry (NP = 2: Cb and Cr from the same pixels), LP pairs per lane.  wgl = workgroup index within the plane's grid.
-template <int SRC, int LEVEL, int NP, int LP>
+// PF: how many trips ahead the source rows are requested.  One covers the memory latency where a trip is long (level
+// 1 from u8 pixels, four workgroups per CU); level 2 has short trips and few of them per wave, and asks two ahead.
+template <int SRC, int LEVEL, int NP, int LP, bool TAP, int PF = 1>
 KHG_DEV void khg_fwd_wg_body(const KhgFwdArgs& a, const KhgFwdPlane* pls, int wgl, KhgFwdSmem<LEVEL, NP, LP>& sh)
 {
     typedef KhgFwdSmem<LEVEL, NP, LP> SM;
@@ -649,16 +690,38 @@ KHG_DEV void khg_fwd_wg_body(const KhgFwdArgs& a, const KhgFwdPlane* pls, int wg
     khg_segment_rows(g.row_begin, g.row_end, g.nseg, seg, &r0, &r1);
     const int k0 = r0 / 2, k1 = r1 / 2;
     const int P0 = SP * KHG_WG_STRIPS * swg;  // first output pair of the workgroup
+    const KhgFwdRows rw = khg_fwd_rows<SRC>(a, g);
+    // loop invariants of the planes, read once
+    int ek0 = KHG_UNIFORM(g.emit_k0), ek1 = KHG_UNIFORM(g.emit_k1);
+    uint32_t sym_step = 2u * (uint32_t)KHG_UNIFORM(g.sym_pitch), ll_step = 8u * (uint32_t)KHG_UNIFORM(g.ll_pitch);
+    KHG_KEEP_SCALAR(ek0);
+    KHG_KEEP_SCALAR(ek1);
+    KHG_KEEP_SCALAR(sym_step);
+    KHG_KEEP_SCALAR(ll_step);
     // byte offsets in the symbol plane from position (k, pair) to (k, w/2 + pair) and to (h/2 + k, pair)
-    const uint32_t right = 2u * (uint32_t)(g.pw / 2), down = 2u * (uint32_t)(g.ph / 2) * (uint32_t)g.sym_pitch;
+    uint32_t right = 2u * (uint32_t)(g.pw / 2), down = 2u * (uint32_t)(g.ph / 2) * (uint32_t)g.sym_pitch;
+    char *symb[NP], *llb[NP];  // the planes' buffers and the dump areas behind them
+    uint32_t symd[NP], lld[NP];
+    for (int n = 0; n < NP; ++n) {
+        symb[n] = (char*)pls[n].sym;
+        llb[n] = (char*)pls[n].ll;
+        symd[n] = KHG_UNIFORM(pls[n].sym_dump);
+        lld[n] = KHG_UNIFORM(pls[n].ll_dump);
+        KHG_KEEP_SCALAR(symb[n]);
+        KHG_KEEP_SCALAR(llb[n]);
+        KHG_KEEP_SCALAR(symd[n]);
+        KHG_KEEP_SCALAR(lld[n]);
+    }
+    int hh_ = KHG_UNIFORM(g.ph / 2), hw_ = KHG_UNIFORM(g.pw / 2);
+    KHG_KEEP_SCALAR(right);
+    KHG_KEEP_SCALAR(down);
+    KHG_KEEP_SCALAR(hh_);
+    KHG_KEEP_SCALAR(hw_);
 
     KhgLift colL[NP][LP][KHG_NSLOT(256)], colH[NP][LP][KHG_NSLOT(256)];
     uint32_t cnts[NP][KHG_NSLOT(256)], seens[NP][KHG_NSLOT(256)];
     int dones[KHG_NSLOT(256)];     // the wave only counts -1, 0, +1 from here on (see khg_hot_done)
-    KhgFwdRaw<SRC, LP> raws[KHG_NSLOT(256)];
-#ifdef KHG_EXP_PF2
-    KhgFwdRaw<SRC, LP> raws2[KHG_NSLOT(256)];  // the rows of the trip after next
-#endif
+    KhgFwdRaw<SRC, LP> raws[PF][KHG_NSLOT(256)];  // the source rows of this trip and of the PF - 1 trips after it
     KhgLaneSrc<LP> lsrc[KHG_NSLOT(256)];
     int pairs[KHG_NSLOT(256)];     // the lane's first pair, clamped to the strip's output pairs
     bool outl[KHG_NSLOT(256)];     // the lane outputs its pairs
@@ -692,12 +755,10 @@ KHG_DEV void khg_fwd_wg_body(const KhgFwdArgs& a, const KhgFwdPlane* pls, int wg
         dones[KHG_SLOT] = 0;
         // rows of the first trip
         uint32_t foa, fob;
-        khg_fwd_row_offsets<SRC>(a, g, k0 - 2, foa, fob);
-        khg_fwd_fetch<SRC, LP>(a, g, raws[KHG_SLOT], foa, fob, lsrc[KHG_SLOT]);
-#ifdef KHG_EXP_PF2
-        khg_fwd_row_offsets<SRC>(a, g, k0 - 1, foa, fob);
-        khg_fwd_fetch<SRC, LP>(a, g, raws2[KHG_SLOT], foa, fob, lsrc[KHG_SLOT]);
-#endif
+        for (int i = 0; i < PF; ++i) {
+            khg_fwd_row_offsets<SRC>(a, g, rw, k0 - 2 + i, foa, fob);
+            khg_fwd_fetch<SRC, LP>(a, g, raws[i][KHG_SLOT], foa, fob, lsrc[KHG_SLOT]);
+        }
         const int lh = LEVEL == 1 ? (int)SM::LHIST : a.lhist, l0 = SM::LHIST_BIAS - lh / 2;  // the bins in use
         for (int n = 0; n < NP; ++n)
             for (int i = l0 + tid; i < l0 + lh; i += 256) {
@@ -717,6 +778,7 @@ KHG_DEV void khg_fwd_wg_body(const KhgFwdArgs& a, const KhgFwdPlane* pls, int wg
         }
     }
     KHG_BARRIER();
+    KHG_FWD_STAMP_HERE(6);
 
     // Row pairs k0-2 .. k1+1 are fed; the column pipeline hands back pair j-2 when pair j goes in.
 #if !defined(KHG_SIM) && defined(KHG_FWD_UNROLL2)
@@ -735,13 +797,9 @@ KHG_DEV void khg_fwd_wg_body(const KhgFwdArgs& a, const KhgFwdPlane* pls, int wg
     const bool idle = false;
 #endif
     auto trip = [&](const int j) __attribute__((always_inline)) {
-        // source rows of the next trip (the same for every thread)
+        // source rows of the trip PF ahead (the same for every thread)
         uint32_t noa, nob;
-#ifdef KHG_EXP_PF2
-        khg_fwd_row_offsets<SRC>(a, g, j + 2, noa, nob);
-#else
-        khg_fwd_row_offsets<SRC>(a, g, j + 1, noa, nob);
-#endif
+        khg_fwd_row_offsets<SRC>(a, g, rw, j + PF, noa, nob);
 #ifdef KHG_EXP_FAKELOAD  // developer experiment: every trip reads the same two rows
         noa = 0; nob = 0;
 #endif
@@ -753,17 +811,14 @@ KHG_DEV void khg_fwd_wg_body(const KhgFwdArgs& a, const KhgFwdPlane* pls, int wg
                 for (int n = 0; n < NP; ++n)
                     KHG_UNROLL
                     for (int p = 0; p < LP; ++p)
-                        khg_fwd_samples<SRC, LP>(raws[KHG_SLOT], lsrc[KHG_SLOT], p, rr, n, E[rr][n][p][KHG_SLOT],
+                        khg_fwd_samples<SRC, LP>(raws[0][KHG_SLOT], lsrc[KHG_SLOT], p, rr, n, E[rr][n][p][KHG_SLOT],
                                                  O[rr][n][p][KHG_SLOT]);
-            // next trip's rows: in flight during this trip's arithmetic (unconditional, also after the last
+            // a later trip's rows: in flight during this trip's arithmetic (unconditional, also after the last
             // trip, where the rows are reflected back into the plane and the loads are simply not used: a
             // condition here would make the loads land in other registers and cost a wait and copies per trip)
-#ifdef KHG_EXP_PF2
-            raws[KHG_SLOT] = raws2[KHG_SLOT];
-            khg_fwd_fetch<SRC, LP>(a, g, raws2[KHG_SLOT], noa, nob, lsrc[KHG_SLOT]);
-#else
-            khg_fwd_fetch<SRC, LP>(a, g, raws[KHG_SLOT], noa, nob, lsrc[KHG_SLOT]);
-#endif
+            KHG_UNROLL
+            for (int i = 0; i + 1 < PF; ++i) raws[i][KHG_SLOT] = raws[i + 1][KHG_SLOT];
+            khg_fwd_fetch<SRC, LP>(a, g, raws[PF - 1][KHG_SLOT], noa, nob, lsrc[KHG_SLOT]);
         }
         // predict 1: d1[p] = o[p] + P1 * (e[p] + e[p+1])
         for (int rr = 0; rr < 2; ++rr)
@@ -849,8 +904,9 @@ KHG_DEV void khg_fwd_wg_body(const KhgFwdArgs& a, const KhgFwdPlane* pls, int wg
                 for (int s = 0; s < SM::NBAND; ++s) words[s] = 0;
                 bool syms = false;
                 if (out)
-                    syms = khg_col_emit<LEVEL, LP, SM::LHIST>(a, pls[n], sh.cnt[n], sh.first[n], cnts[n][KHG_SLOT],
-                                                              seens[n][KHG_SLOT], dones[KHG_SLOT] != 0, pair, k, s2L, d2L,
+                    syms = khg_col_emit<LEVEL, LP, SM::LHIST, TAP>(a, pls[n], sh.cnt[n], sh.first[n], cnts[n][KHG_SLOT],
+                                                              seens[n][KHG_SLOT], dones[KHG_SLOT] != 0, k >= ek0 && k < ek1, hh_, hw_,
+                                                              right, down, pair, k, s2L, d2L,
                                                               s2H, d2H, rdv, symo[KHG_SLOT], llv, words);
                 // The trip's stores, outside every condition: the compiler then knows how many stores follow the
                 // loads of the next trip's rows and waits for those loads alone (behind a branch they made it wait
@@ -859,14 +915,14 @@ KHG_DEV void khg_fwd_wg_body(const KhgFwdArgs& a, const KhgFwdPlane* pls, int wg
                 // 16 bytes).
                 if (LEVEL == 1) {
 #ifdef KHG_EXP_NOSTORE  // developer experiment: every store goes to the dump area
-                    const uint32_t o = pls[n].ll_dump + (uint32_t)(8 * LP * tid);
+                    const uint32_t o = lld[n] + (uint32_t)(8 * LP * tid);
 #else
-                    const uint32_t o = out ? llo[KHG_SLOT] : pls[n].ll_dump + (uint32_t)(8 * LP * tid);
+                    const uint32_t o = out ? llo[KHG_SLOT] : lld[n] + (uint32_t)(8 * LP * tid);
 #endif
 #ifdef KHG_EXP_NTSTORE
-                    for (int p = 0; p < LP; ++p) __builtin_nontemporal_store(llv[p], (double*)((char*)pls[n].ll + o) + p);
+                    for (int p = 0; p < LP; ++p) __builtin_nontemporal_store(llv[p], (double*)(llb[n] + o) + p);
 #else
-                    __builtin_memcpy(KHG_ASSUME_ALIGNED((char*)pls[n].ll + o, LP == 2 ? 16 : 8), llv, sizeof llv);
+                    __builtin_memcpy(KHG_ASSUME_ALIGNED(llb[n] + o, LP == 2 ? 16 : 8), llv, sizeof llv);
 #endif
                 }
                 KHG_UNROLL
@@ -874,11 +930,11 @@ KHG_DEV void khg_fwd_wg_body(const KhgFwdArgs& a, const KhgFwdPlane* pls, int wg
                     const int b4 = s + 4 - SM::NBAND;
                     const uint32_t boff = b4 == 0 ? 0u : b4 == 1 ? right : b4 == 2 ? down : down + right;
 #ifdef KHG_EXP_NOSTORE
-                    const uint32_t o = pls[n].sym_dump + (uint32_t)(1024 * s + (LP == 2 ? 4 : 2) * tid) + 0 * boff;
+                    const uint32_t o = symd[n] + (uint32_t)(1024 * s + (LP == 2 ? 4 : 2) * tid) + 0 * boff;
 #else
-                    const uint32_t o = syms ? symo[KHG_SLOT] + boff : pls[n].sym_dump + (uint32_t)(1024 * s + (LP == 2 ? 4 : 2) * tid);
+                    const uint32_t o = syms ? symo[KHG_SLOT] + boff : symd[n] + (uint32_t)(1024 * s + (LP == 2 ? 4 : 2) * tid);
 #endif
-                    char* at = (char*)pls[n].sym + o;
+                    char* at = symb[n] + o;
 #ifdef KHG_EXP_NTSTORE
                     if (LP == 2) __builtin_nontemporal_store(words[s], (uint32_t*)at);
                     else __builtin_nontemporal_store((int16_t)words[s], (int16_t*)at);
@@ -888,8 +944,8 @@ KHG_DEV void khg_fwd_wg_body(const KhgFwdArgs& a, const KhgFwdPlane* pls, int wg
 #endif
                 }
             }
-            symo[KHG_SLOT] += 2u * (uint32_t)g.sym_pitch;
-            llo[KHG_SLOT] += 8u * (uint32_t)g.ll_pitch;
+            symo[KHG_SLOT] += sym_step;
+            llo[KHG_SLOT] += ll_step;
         }
         if (k >= k0 && k < k1) {
             const int t = k - k0 + 1;  // row pairs this segment has emitted
@@ -921,6 +977,7 @@ KHG_DEV void khg_fwd_wg_body(const KhgFwdArgs& a, const KhgFwdPlane* pls, int wg
         for (int j = k0 - 2; j <= jend; ++j) trip(j);
 #endif
 
+    KHG_FWD_STAMP_HERE(7);
     KHG_FOR_THREADS(256)
     {
         for (int n = 0; n < NP; ++n) khg_tally_flush<SM::LHIST>(sh.cnt[n], cnts[n][KHG_SLOT]);
@@ -942,20 +999,15 @@ KHG_DEV void khg_fwd_wg_body(const KhgFwdArgs& a, const KhgFwdPlane* pls, int wg
     }
 }
 
+#ifndef KHG_FWD_PF_L2
+#define KHG_FWD_PF_L2 2
+#endif
 // Launch kinds.
 enum { KHG_FWD_RGB = 0, KHG_FWD_PLANES1 = 1, KHG_FWD_PLANES2 = 2, KHG_FWD_BGR = 3 };
 
-#if defined(KHG_TIMING) && !defined(KHG_SIM)
-// developer build: per-workgroup start / end stamps (100 MHz), hardware id and shader-clock cycles of the last forward launch
-__device__ uint32_t khg_dbg_fwd[8 * 8192];
-#define KHG_FWD_STAMP(wg, slot, v) \
-    if (threadIdx.x == 0 && (wg) < 8192) khg_dbg_fwd[8 * (wg) + (slot)] = (v)
-#else
-#define KHG_FWD_STAMP(wg, slot, v)
-#endif
 
 // Workgroup `wg` of a launch: which plane it belongs to, and its body.
-template <int KIND, int LP, int LPC>
+template <int KIND, int LP, int LPC, bool TAP>
 KHG_DEV void khg_fwd_launch_body(const KhgFwdArgs& a, int wg, KhgFwdSmemAny& sh)
 {
 #ifndef KHG_EXP_NOREMAP
@@ -967,18 +1019,18 @@ KHG_DEV void khg_fwd_launch_body(const KhgFwdArgs& a, int wg, KhgFwdSmemAny& sh)
     KHG_FWD_STAMP(wg, 4, (uint32_t)__builtin_amdgcn_s_memtime());
     if constexpr (KIND == KHG_FWD_RGB) {
         if (a.nplanes < 2 || wg < a.pl[1].wg0)
-            khg_fwd_wg_body<KHG_SRC_Y, 1, 1, LP>(a, &a.pl[0], wg, *(KhgFwdSmem<1, 1, LP>*)&sh);
-        else khg_fwd_wg_body<KHG_SRC_C, 1, 2, LPC>(a, &a.pl[1], wg - a.pl[1].wg0, *(KhgFwdSmem<1, 2, LPC>*)&sh);
+            khg_fwd_wg_body<KHG_SRC_Y, 1, 1, LP, TAP>(a, &a.pl[0], wg, *(KhgFwdSmem<1, 1, LP>*)&sh);
+        else khg_fwd_wg_body<KHG_SRC_C, 1, 2, LPC, TAP>(a, &a.pl[1], wg - a.pl[1].wg0, *(KhgFwdSmem<1, 2, LPC>*)&sh);
     } else if constexpr (KIND == KHG_FWD_BGR) {
         if (a.nplanes < 2 || wg < a.pl[1].wg0)
-            khg_fwd_wg_body<KHG_SRC_Y_BGR, 1, 1, LP>(a, &a.pl[0], wg, *(KhgFwdSmem<1, 1, LP>*)&sh);
-        else khg_fwd_wg_body<KHG_SRC_C_BGR, 1, 2, LPC>(a, &a.pl[1], wg - a.pl[1].wg0, *(KhgFwdSmem<1, 2, LPC>*)&sh);
+            khg_fwd_wg_body<KHG_SRC_Y_BGR, 1, 1, LP, TAP>(a, &a.pl[0], wg, *(KhgFwdSmem<1, 1, LP>*)&sh);
+        else khg_fwd_wg_body<KHG_SRC_C_BGR, 1, 2, LPC, TAP>(a, &a.pl[1], wg - a.pl[1].wg0, *(KhgFwdSmem<1, 2, LPC>*)&sh);
     } else {
         int p = 0;
         while (p + 1 < a.nplanes && wg >= a.pl[p + 1].wg0) ++p;
         if constexpr (KIND == KHG_FWD_PLANES1)
-            khg_fwd_wg_body<KHG_SRC_PLANE, 1, 1, LP>(a, &a.pl[p], wg - a.pl[p].wg0, *(KhgFwdSmem<1, 1, LP>*)&sh);
-        else khg_fwd_wg_body<KHG_SRC_PLANE, 2, 1, LP>(a, &a.pl[p], wg - a.pl[p].wg0, *(KhgFwdSmem<2, 1, LP>*)&sh);
+            khg_fwd_wg_body<KHG_SRC_PLANE, 1, 1, LP, TAP>(a, &a.pl[p], wg - a.pl[p].wg0, *(KhgFwdSmem<1, 1, LP>*)&sh);
+        else khg_fwd_wg_body<KHG_SRC_PLANE, 2, 1, LP, TAP, KHG_FWD_PF_L2>(a, &a.pl[p], wg - a.pl[p].wg0, *(KhgFwdSmem<2, 1, LP>*)&sh);
     }
     KHG_FWD_STAMP(wg, 1, (uint32_t)wall_clock64());
     KHG_FWD_STAMP(wg, 5, (uint32_t)__builtin_amdgcn_s_memtime());

@@ -180,6 +180,9 @@ static inline void khg_fwd_plane(KhgFwdPlane* pl, const KhgWorkspace& ws, int ro
 #ifndef KHG_FWD_SLOTS
 #define KHG_FWD_SLOTS 1024
 #endif
+#ifndef KHG_FWD_SLOTS_L2
+#define KHG_FWD_SLOTS_L2 512
+#endif
 #ifndef KHG_FWD_SLOTS_LP2
 #define KHG_FWD_SLOTS_LP2 1024
 #endif
@@ -232,7 +235,8 @@ static inline int khg_plan_groups(KhgGridGroup* g, int ngroup, int slots)
 }
 
 // Grid of a forward launch: group i starts at plane first[i] and holds count[i] planes.
-static inline void khg_fwd_plan_grid(KhgFwdArgs* a, int ngroup, const int* first, const int* count, const int* weight)
+static inline void khg_fwd_plan_grid(KhgFwdArgs* a, int ngroup, const int* first, const int* count, const int* weight,
+                                     int slots = 0)
 {
     KhgGridGroup g[3];
     for (int i = 0; i < ngroup; ++i) {
@@ -240,7 +244,9 @@ static inline void khg_fwd_plan_grid(KhgFwdArgs* a, int ngroup, const int* first
         g[i].pw = pl.pw; g[i].span = pl.row_end - pl.row_begin; g[i].weight = weight[i];
         g[i].strip_pairs = KHG_STRIP_PAIRS_LP(count[i] == 2 ? a->lpc : a->lp);
     }
-    a->nwg = khg_plan_groups(g, ngroup, a->lp == 2 ? KHG_FWD_SLOTS_LP2 : KHG_FWD_SLOTS);
+    a->tap = 0;
+    for (int p = 0; p < a->nplanes; ++p) a->tap |= a->pl[p].coef != nullptr;
+    a->nwg = khg_plan_groups(g, ngroup, slots ? slots : a->lp == 2 ? KHG_FWD_SLOTS_LP2 : KHG_FWD_SLOTS);
     for (int i = 0; i < ngroup; ++i)
         for (int j = 0; j < count[i]; ++j) {
             KhgFwdPlane& o = a->pl[first[i] + j];
@@ -294,7 +300,9 @@ static inline KhgFwdArgs khg_fwd_args_planes(const KhgWorkspace& ws, int rows, i
     a.nplanes = 3;
     a.lp = a.lpc = khg_fwd_lp_for(a);
     a.lhist = level == 1 ? 256 : (lvl == 0 ? 2048 : 1024);  // Normal preset: luma LL symbols reach 1009 (255 * 4 / 1.011)
-    khg_fwd_plan_grid(&a, 3, first, count, weight);
+    // Level 2 is a quarter of the samples: spread over every slot of the chip a wave would walk six row pairs and
+    // warm up its column pipelines over four more.
+    khg_fwd_plan_grid(&a, 3, first, count, weight, level == 2 ? KHG_FWD_SLOTS_L2 : 0);
     return a;
 }
 

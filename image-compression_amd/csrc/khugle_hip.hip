@@ -24,11 +24,15 @@
 #ifndef KHG_FWD_LP2_WAVES
 #define KHG_FWD_LP2_WAVES 4  // workgroups per CU (waves per SIMD) the two-pair kernels are compiled for; see KHG_FWD_SLOTS_LP2
 #endif
-template <int KIND, int LP, int LPC>
-__global__ __launch_bounds__(256, LP == 2 ? KHG_FWD_LP2_WAVES : 4) void khg_fwd_kernel(KhgFwdArgs a)
+#ifndef KHG_FWD_L2_WAVES
+#define KHG_FWD_L2_WAVES 2  // level 2 is planned for KHG_FWD_SLOTS_L2 workgroups: two per CU
+#endif
+// TAP: the instantiation that also stores every coefficient as f64 (debug taps, the drop-in CompressImage).
+template <int KIND, int LP, int LPC, bool TAP>
+__global__ __launch_bounds__(256, KIND == KHG_FWD_PLANES2 ? KHG_FWD_L2_WAVES : LP == 2 ? KHG_FWD_LP2_WAVES : 4) void khg_fwd_kernel(KhgFwdArgs a)
 {
     __shared__ KhgFwdSmemAny sh;
-    khg_fwd_launch_body<KIND, LP, LPC>(a, (int)blockIdx.x, sh);
+    khg_fwd_launch_body<KIND, LP, LPC, TAP>(a, (int)blockIdx.x, sh);
 }
 
 __global__ __launch_bounds__(256) void khg_table_kernel(KhgTableArgs a)
@@ -456,8 +460,13 @@ static int khg_end(khg_ctx* c, hipStream_t st, int pending)
 template <int KIND>
 static void khg_launch_fwd(const KhgFwdArgs& a, hipStream_t st)
 {
-    if (a.lp == 2) hipLaunchKernelGGL((khg_fwd_kernel<KIND, 2, KHG_FWD_LPC>), dim3(a.nwg), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((khg_fwd_kernel<KIND, 1, 1>), dim3(a.nwg), dim3(256), 0, st, a);
+    if (a.tap) {
+        if (a.lp == 2) hipLaunchKernelGGL((khg_fwd_kernel<KIND, 2, KHG_FWD_LPC, true>), dim3(a.nwg), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((khg_fwd_kernel<KIND, 1, 1, true>), dim3(a.nwg), dim3(256), 0, st, a);
+    } else {
+        if (a.lp == 2) hipLaunchKernelGGL((khg_fwd_kernel<KIND, 2, KHG_FWD_LPC, false>), dim3(a.nwg), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((khg_fwd_kernel<KIND, 1, 1, false>), dim3(a.nwg), dim3(256), 0, st, a);
+    }
 }
 
 // Colour + both DWT levels + quantiser + histograms for the three components.

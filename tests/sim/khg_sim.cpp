@@ -56,8 +56,8 @@ template <int KIND>
 void run_fwd(const KhgFwdArgs& a) {
     KhgFwdSmemAny* sh = new KhgFwdSmemAny;
     for (int wg = 0; wg < a.nwg; ++wg) {
-        if (a.lp == 2) khg_fwd_launch_body<KIND, 2, KHG_FWD_LPC>(a, wg, *sh);
-        else khg_fwd_launch_body<KIND, 1, 1>(a, wg, *sh);
+        if (a.lp == 2) khg_fwd_launch_body<KIND, 2, KHG_FWD_LPC, true>(a, wg, *sh);
+        else khg_fwd_launch_body<KIND, 1, 1, true>(a, wg, *sh);
     }
     delete sh;
 }

@@ -25,10 +25,6 @@ w = buf.reshape(-1, 8)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 nl = int(sys.argv[2]) if len(sys.argv) > 2 else 688
 w = w[:n]
-if os.environ.get("KHG_REMAP", "1") == "1":  # stamps are stored by hardware workgroup id; classify by the work index
-    q, r = divmod(n, 8)
-    work = np.array([(x % 8) * (q + 1) + x // 8 if x % 8 < r else r * (q + 1) + (x % 8 - r) * q + x // 8 for x in range(n)])
-    w = w[np.argsort(work)]
 t0 = w[:, 0].min()
 st = (w[:, 0] - t0).astype(np.int64) / 100.0  # us
 en = (w[:, 1] - t0).astype(np.int64) / 100.0
@@ -52,6 +48,10 @@ for i in range(n):
 for k in list(mix)[:12]:
     print(k, mix[k])
 print("span of the launch %.1f us" % (en.max() - st.min()))
+pro = (w[:, 6] - w[:, 0]).astype(np.int64) / 100.0
+loop = (w[:, 7] - w[:, 6]).astype(np.int64) / 100.0
+epi = (w[:, 1] - w[:, 7]).astype(np.int64) / 100.0
+print("prologue mean %.1f max %.1f  loop (wave 0) mean %.1f max %.1f  epilogue mean %.1f max %.1f us" % (pro.mean(), pro.max(), loop.mean(), loop.max(), epi.mean(), epi.max()))
 cyc = (w[:, 5].astype(np.int64) - w[:, 4].astype(np.int64)) & 0xFFFFFFFF
 ghz = cyc / np.maximum(du, 1e-3) / 1e3
 print("shader clock held inside the workgroups: median %.2f GHz (min %.2f, max %.2f)" % (np.median(ghz), ghz.min(), ghz.max()))
