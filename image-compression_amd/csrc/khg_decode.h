@@ -564,7 +564,8 @@ template <int MO>
 struct KhgDecSmem {
     uint8_t len8[KHG_LUT_SIZE];                    // see khg_len_at
     uint32_t stage[KHG_STAGE_LDS];
-    uint32_t mask[KHG_SUB_WORDS * KHG_DEC_BLOCK];  // word-major: thread t's word w at [w * 256 + t]
+    uint32_t mask[(KHG_SUB_WORDS + 1) * KHG_DEC_BLOCK];  // word-major: thread t's word w at [w * 256 + t]; a subsequence
+                                                         // that starts inside a staged word reaches into one more
     uint16_t map[MO * KHG_DEC_BLOCK];              // offset-major: thread t's entry for offset o at [o * 256 + t]
 };
 
@@ -644,143 +645,190 @@ KHG_DEV void khg_dec_map_body(const KhgDecArgs& a, uint32_t blk, KhgDecSmem<MO>&
     const KhgBitsL bits = khg_dec_stage_lens(a, p, blk_begin, sh);
     KHG_BARRIER();
 
+    // A subsequence is walked one 32-bit word of the staged stream at a time: the word, its successor and the
+    // word's start marks sit in registers while the codewords that begin in it are stepped over, so a step costs one
+    // LDS access (the code length under the bit window) instead of four (two stream words, the mark word, the
+    // length).  The LDS pipe, not its latency, is what this kernel waits for.  Positions are kept relative to the
+    // first staged word of the subsequence: lr = (position in the subsequence) + s0, the same s0 < 32 for every
+    // thread (subsequences are 256 bits, a whole number of words, apart).
+    const uint32_t s0 = (blk_begin - bits.bias) & 31u;
     KHG_FOR_THREADS(256)
     {
         const uint32_t sub_begin = blk_begin + (uint32_t)tid * KHG_SUB_BITS;
         const uint32_t end = sub_begin + KHG_SUB_BITS < nbits ? sub_begin + KHG_SUB_BITS : nbits;
+        const uint32_t lr_of = s0 - sub_begin;            // lr = pos + lr_of
+        const uint32_t end_lr = sub_begin < end ? end + lr_of : 0;  // first lr behind the subsequence (or the stream)
+        const uint32_t nb_lr = nbits + lr_of;             // first lr behind the stream (sub_begin < nbits: no wrap)
+        const uint32_t wbase = (uint32_t)tid * KHG_SUB_WORDS;  // first staged word of the subsequence
         uint16_t* map = &sh.map[tid];
         uint32_t* mask = &sh.mask[tid];
-        // 1. first codeword from every start offset: where does it land?
-        for (uint32_t o = 0; o < M; ++o) {
-            uint32_t pos = sub_begin + o;
-            uint16_t e = khg_map_entry(KHG_OFF_NONE, 0);
-            if (pos < end) {
-                uint32_t len = khg_len_at(bits, sh.len8, glut, lut2, left, right, tsym, pos);
-                if (len) e = khg_map_entry(KHG_OFF_TEMP, o + len);  // landing offset < 2 * 56
+        // 1. first codeword from every start offset: where does it land?  The offsets lie in the first three words.
+        {
+            const uint32_t w0 = bits.stage[khg_stage_slot(wbase)], w1 = bits.stage[khg_stage_slot(wbase + 1)],
+                           w2 = bits.stage[khg_stage_slot(wbase + 2)], w3 = bits.stage[khg_stage_slot(wbase + 3)];
+            for (uint32_t o = 0; o < M; ++o) {
+                const uint32_t lr = s0 + o, j = lr >> 5, sh_ = lr & 31u;
+                uint16_t e = khg_map_entry(KHG_OFF_NONE, 0);
+                if (lr < end_lr) {
+                    const uint32_t hi = j == 0 ? w0 : j == 1 ? w1 : w2, lo = j == 0 ? w1 : j == 1 ? w2 : w3;
+                    const uint32_t win = (uint32_t)(((((uint64_t)hi << 32) | lo) << sh_) >> 32);
+                    uint32_t len = sh.len8[win >> (32 - KHG_LUT_BITS)];
+                    if (len == 0) {  // longer than the first-level table: the general decoder
+                        int sy;
+                        len = khg_decode_one(bits, glut, lut2, left, right, tsym, sub_begin + o, &sy);
+                    } else if (lr + len > nb_lr) {
+                        len = 0;  // the stream ends inside this codeword
+                    }
+                    if (len) e = khg_map_entry(KHG_OFF_TEMP, o + len);  // landing offset < 2 * 56
+                }
+                map[o * KHG_DEC_BLOCK] = e;
             }
-            map[o * KHG_DEC_BLOCK] = e;
         }
-        // 2. offsets whose first codeword leaves the first M bits run on.  The first such run (from the
-        //    highest offset) goes through the whole subsequence and records its codeword starts.
+        // 2. offsets whose first codeword leaves the first M bits run on.  The first such run (from the highest
+        //    offset) goes through the whole subsequence and records its codeword starts; every other run stops as
+        //    soon as it lands on one of them (inside a run of the 1-bit code every position is one).  Most rejoin
+        //    within a few codewords; a stretch of near-equal code lengths has one run per residue class that never
+        //    does.
+        //    The inner loops are straight-line code with one exit at the bottom (the lanes of a wave stay in one
+        //    loop); whatever is rare -- a code beyond the first-level table, the end of the stream -- leaves them
+        //    and is dealt with once per word.
         int oo = (int)M;
         bool have_main = false;
         uint32_t main_arr = KHG_OFF_NONE;
-        while (oo > 0) {
-            --oo;
-            const uint16_t e0 = map[oo * KHG_DEC_BLOCK];
-            if (khg_map_arr(e0) != KHG_OFF_TEMP || khg_map_cnt(e0) < M) continue;
-            uint32_t pos = sub_begin + khg_map_cnt(e0), n = 1;
-            bool dead = false;
-            KhgCursor cur;
-            if (pos < end) khg_cur_init(cur, bits, pos);
-            for (uint32_t w = 0; w < KHG_SUB_WORDS; ++w) mask[w * KHG_DEC_BLOCK] = 0;
-            // each trip: a run of the 1-bit code (possibly empty), then one other codeword
-            while (pos < end) {
-                uint32_t rel = pos - sub_begin;
-                const uint32_t r = khg_cur_runlen(cur, onebit, end - pos);
-                if (r) {  // r codeword starts at once
-                    const uint64_t m = khg_mask_range(rel, r);
-                    khg_lds_or(&mask[(rel >> 5) * KHG_DEC_BLOCK], (uint32_t)(m >> 32));
-                    if ((uint32_t)m) khg_lds_or(&mask[((rel >> 5) + 1) * KHG_DEC_BLOCK], (uint32_t)m);
-                    khg_cur_skip(cur, bits, r);
-                    pos += r;
-                    n += r;
-                    rel += r;
-                }
-                if (pos < end && r < 32) {  // a run cut at 32 may simply go on
-                    uint32_t len = khg_cur_step(cur, bits, sh.len8, glut, lut2, left, right, tsym);
-                    if (len == 0) {
-                        dead = true;
-                        break;
-                    }
-                    khg_lds_or(&mask[(rel >> 5) * KHG_DEC_BLOCK], 0x80000000u >> (rel & 31));
-                    pos += len;
-                    ++n;
-                }
-            }
-            if (dead || pos >= nbits) main_arr = KHG_OFF_NONE;
-            else main_arr = pos - (sub_begin + KHG_SUB_BITS);  // pos >= sub_begin + 512, overshoot < M
-            map[oo * KHG_DEC_BLOCK] = khg_map_entry(main_arr, n);
-            have_main = true;
-            break;
-        }
-#ifdef KHG_TIMING
-        if (tid == 0) a.blk[blk].pad_[4] = (uint32_t)wall_clock64();
-#endif
-        //    Every other such run stops as soon as it lands on a recorded start (inside a run of the 1-bit
-        //    code every position is one, so no run handling is needed here).  Most rejoin within a few
-        //    codewords; a stretch of near-equal code lengths has one run per residue class that never does.
-        //    No bit window is carried from step to step: a step reads the two stream words under its position
-        //    afresh, which is fewer instructions than keeping a window topped up.  (Advancing several runs side
-        //    by side to overlap their LDS round trips was slower: the lanes of a wave then wait for the longest
-        //    of all of them.)
-        while (have_main) {
+        for (uint32_t w = 0; w <= KHG_SUB_WORDS; ++w) mask[w * KHG_DEC_BLOCK] = 0;
+        const uint32_t runx = onebit < 0 ? 0xFFFFFFFFu : 0u;       // planes without a 1-bit code: no runs
+        const uint32_t runflip = onebit > 0 ? 0xFFFFFFFFu : 0u;    // the run's bits read as zeros
+        for (;;) {
             bool found = false;
-            uint32_t ro = 0, rpos = sub_begin;
+            uint32_t ro = 0, lr = 0;
             while (oo > 0) {
                 --oo;
                 const uint16_t e0 = map[oo * KHG_DEC_BLOCK];
                 if (khg_map_arr(e0) == KHG_OFF_TEMP && khg_map_cnt(e0) >= M) {
                     found = true;
                     ro = (uint32_t)oo;
-                    rpos = sub_begin + khg_map_cnt(e0);
+                    lr = s0 + khg_map_cnt(e0);
                     break;
                 }
             }
             if (!found) break;
-            uint32_t rn = 1, rjoin = 0xFFFFFFFFu;
-            bool rdead = false, ract = rpos < end;
-            while (ract) {  // one exit, at the bottom: the lanes of a wave stay in one loop
-                const uint32_t rel = rpos - sub_begin;  // < KHG_SUB_BITS
-                const uint32_t mw = mask[(rel >> 5) * KHG_DEC_BLOCK];
-                const uint32_t w = (rpos - bits.bias) >> 5;
-                const uint32_t wa = bits.stage[khg_stage_slot(w)], wb = bits.stage[khg_stage_slot(w + 1)];
-                const uint32_t win = (uint32_t)(((((uint64_t)wa << 32) | wb) << ((rpos - bits.bias) & 31)) >> 32);
-                const uint32_t len = sh.len8[win >> (32 - KHG_LUT_BITS)];
-                if ((mw << (rel & 31)) & 0x80000000u) {  // a codeword start of the first run: identical from here on
-                    rjoin = rel;
-                    ract = false;
-                } else if (len == 0) {  // longer than the first-level table: the general decoder
-                    int s;
-                    const uint32_t l2 = khg_decode_one(bits, glut, lut2, left, right, tsym, rpos, &s);
-                    if (l2 == 0) {
-                        rdead = true;
-                        ract = false;
-                    } else {
-                        rpos += l2;
-                        ++rn;
-                        ract = rpos < end;
+            uint32_t n = 1, join = 0xFFFFFFFFu;
+            bool dead = false;
+            if (!have_main) {
+                // the recording run; a run of the 1-bit code is stepped over at once (as far as the word goes)
+                if (lr < end_lr) {
+                    uint32_t j = lr >> 5, adv = 0;
+                    uint32_t wa = bits.stage[khg_stage_slot(wbase + j)];
+                    for (;;) {  // one word of the stream per trip
+                        const uint32_t wb = bits.stage[khg_stage_slot(wbase + j + 1)];
+                        const uint32_t lim = end_lr < 32u * (j + 1) ? end_lr : 32u * (j + 1);  // this trip's positions end here
+                        uint32_t acc = 0;
+                        do {  // the codewords that begin in word j
+                            const uint32_t sh_ = lr & 31u;
+                            const uint32_t win = (uint32_t)(((((uint64_t)wa << 32) | wb) << sh_) >> 32);
+                            const uint32_t x = (win ^ runflip) | runx;
+                            uint32_t r = x ? (uint32_t)__builtin_clz(x) : 32u;  // the run of the 1-bit code here
+                            r = r > lim - lr ? lim - lr : r;
+                            const uint32_t len = sh.len8[win >> (32 - KHG_LUT_BITS)];  // 0: beyond the table
+                            adv = r ? r : len;
+                            const uint32_t starts = r ? r : (len ? 1u : 0u);
+                            acc |= (uint32_t)(0xFFFFFFFF00000000ull >> starts) >> sh_;  // `starts` ones from here on
+                            lr += adv;
+                            n += starts;
+                        } while (adv != 0 && lr < lim);
+                        if (adv == 0) {  // a code beyond the first-level table (or the stream's ragged end)
+                            int sy;
+                            const uint32_t len = khg_decode_one(bits, glut, lut2, left, right, tsym, lr - lr_of, &sy);
+                            if (len == 0) {
+                                dead = true;
+                            } else {
+                                acc |= 0x80000000u >> (lr & 31u);
+                                lr += len;
+                                ++n;
+                            }
+                        }
+                        mask[j * KHG_DEC_BLOCK] |= acc;  // (a word is entered twice only behind a long code that ends in it)
+                        if (dead || lr >= end_lr) break;
+                        const uint32_t jn = lr >> 5;
+                        if (jn != j) wa = jn == j + 1 ? wb : bits.stage[khg_stage_slot(wbase + jn)];
+                        j = jn;
                     }
-                } else if (rpos + len > nbits) {  // the stream ends inside this codeword
-                    rdead = true;
-                    ract = false;
-                } else {
-                    rpos += len;
-                    ++rn;
-                    ract = rpos < end;
+                    if (!dead && lr > nb_lr) {  // the stream ends inside the last codeword: not a codeword, not a start
+                        dead = true;
+                        --n;
+                        const uint32_t at = lr - adv;
+                        mask[(at >> 5) * KHG_DEC_BLOCK] &= ~(0x80000000u >> (at & 31u));
+                    }
+                }
+            } else if (lr < end_lr) {
+                uint32_t j = lr >> 5;
+                uint32_t wa = bits.stage[khg_stage_slot(wbase + j)];
+                for (;;) {
+                    const uint32_t wb = bits.stage[khg_stage_slot(wbase + j + 1)];
+                    const uint32_t mw = mask[j * KHG_DEC_BLOCK];
+                    const uint32_t lim = end_lr < 32u * (j + 1) ? end_lr : 32u * (j + 1);
+                    uint32_t t, len;
+                    do {
+                        const uint32_t sh_ = lr & 31u;
+                        const uint32_t win = (uint32_t)(((((uint64_t)wa << 32) | wb) << sh_) >> 32);
+                        t = mw << sh_;  // top bit: a start of the recording run, identical from here on
+                        len = sh.len8[win >> (32 - KHG_LUT_BITS)];
+                        len = (int32_t)t < 0 ? 0u : len;
+                        lr += len;
+                        n += len ? 1u : 0u;
+                    } while (len != 0 && lr < lim);
+                    if ((int32_t)t < 0) {
+                        join = lr;
+                        break;
+                    }
+                    if (len == 0) {  // a code beyond the first-level table
+                        int sy;
+                        const uint32_t l2 = khg_decode_one(bits, glut, lut2, left, right, tsym, lr - lr_of, &sy);
+                        if (l2 == 0) {
+                            dead = true;
+                            break;
+                        }
+                        lr += l2;
+                        ++n;
+                    }
+                    if (lr >= end_lr) break;
+                    const uint32_t jn = lr >> 5;
+                    if (jn != j) wa = jn == j + 1 ? wb : bits.stage[khg_stage_slot(wbase + jn)];
+                    j = jn;
+                }
+                if (!dead && join == 0xFFFFFFFFu && lr > nb_lr) {  // the stream ends inside the last codeword
+                    dead = true;
+                    --n;
                 }
             }
-            uint32_t arr, n = rn;
-            if (rjoin != 0xFFFFFFFFu) {
-                const uint32_t wq = rjoin >> 5, bit = 0x80000000u >> (rjoin & 31);
+            uint32_t arr;
+            if (join != 0xFFFFFFFFu) {
+                const uint32_t wq = join >> 5, bit = 0x80000000u >> (join & 31u);
                 uint32_t rest = (uint32_t)__builtin_popcount(mask[wq * KHG_DEC_BLOCK] & (bit | (bit - 1)));
-                for (uint32_t w2 = wq + 1; w2 < KHG_SUB_WORDS; ++w2)
+                for (uint32_t w2 = wq + 1; w2 <= KHG_SUB_WORDS; ++w2)
                     rest += (uint32_t)__builtin_popcount(mask[w2 * KHG_DEC_BLOCK]);
                 n += rest;
                 arr = main_arr;
-            } else if (rdead || rpos >= nbits) {
+            } else if (dead || lr >= nb_lr) {
                 arr = KHG_OFF_NONE;
             } else {
-                arr = rpos - (sub_begin + KHG_SUB_BITS);
+                arr = lr - (s0 + KHG_SUB_BITS);  // behind the subsequence: an overshoot < M
+            }
+            if (!have_main) {
+                main_arr = arr;
+                have_main = true;
+#ifdef KHG_TIMING
+                if (tid == 0) a.blk[blk].pad_[4] = (uint32_t)wall_clock64();
+#endif
             }
             map[ro * KHG_DEC_BLOCK] = khg_map_entry(arr, n);
         }
         // 3. the other offsets reuse the entry of the offset their first codeword lands on
-        for (uint32_t oo = M; oo-- > 0;) {
-            const uint16_t e0 = map[oo * KHG_DEC_BLOCK];
+        for (uint32_t o3 = M; o3-- > 0;) {
+            const uint16_t e0 = map[o3 * KHG_DEC_BLOCK];
             if (khg_map_arr(e0) != KHG_OFF_TEMP) continue;
-            const uint16_t r = map[khg_map_cnt(e0) * KHG_DEC_BLOCK];  // landing offset > oo: already final
-            map[oo * KHG_DEC_BLOCK] = khg_map_entry(khg_map_arr(r), khg_map_cnt(r) + 1);
+            const uint16_t r = map[khg_map_cnt(e0) * KHG_DEC_BLOCK];  // landing offset > o3: already final
+            map[o3 * KHG_DEC_BLOCK] = khg_map_entry(khg_map_arr(r), khg_map_cnt(r) + 1);
         }
 #ifdef KHG_TIMING
         if (tid == 0) a.blk[blk].pad_[5] = (uint32_t)wall_clock64();
