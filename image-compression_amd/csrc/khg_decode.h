@@ -1258,10 +1258,17 @@ KHG_DEV void khg_dec_write_body(const KhgDecArgs& a, uint32_t blk, KhgDecWriteSm
     }
     KHG_FOR_THREADS(256)
     {
-        const uint32_t off = offs[KHG_SLOT], cnt = sh.pre[tid + 1] - sh.pre[tid];
-        if (off != KHG_OFF_NONE && cnt) {
+        // Start and count come from the walk table -- from the map kernel, or, for a file with an index, from the
+        // file, which may say anything: a subsequence holds at most one codeword per bit from its start offset on,
+        // and a codeword that does not begin inside the subsequence is not this thread's, whatever the count says
+        // (so the cursor never leaves the staged span and no thread decodes more than its 256 bits).
+        const uint32_t off = offs[KHG_SLOT];
+        uint32_t cnt = sh.pre[tid + 1] - sh.pre[tid];
+        if (off < KHG_SUB_BITS && cnt > KHG_SUB_BITS - off) cnt = KHG_SUB_BITS - off;
+        if (off < KHG_SUB_BITS && cnt) {
             const uint32_t o = a.blk[blk].out + sh.pre[tid];
             const uint32_t pos = blk_begin + (uint32_t)tid * KHG_SUB_BITS + off;
+            const uint32_t sub_end = blk_begin + ((uint32_t)tid + 1) * KHG_SUB_BITS;
             const uint32_t lim = a.n[p];
             const uint32_t todo = o >= lim ? 0 : (cnt < lim - o ? cnt : lim - o);  // never store past the plane
             int16_t* q = a.sym[p] + o;
@@ -1272,12 +1279,13 @@ KHG_DEV void khg_dec_write_body(const KhgDecArgs& a, uint32_t blk, KhgDecWriteSm
             uint32_t i = 0;
             bool go = todo != 0;
             while (go) {  // one exit, at the bottom
-                const uint32_t r = khg_cur_runlen(cur, onebit, todo - i);  // 0..32
+                const uint32_t room = sub_end - cur.pos;  // > 0 here
+                const uint32_t r = khg_cur_runlen(cur, onebit, todo - i < room ? todo - i : room);  // 0..32
                 if (r) {
                     khg_cur_skip(cur, bits, r);
                     i += r;
                 }
-                go = i < todo;
+                go = i < todo && cur.pos < sub_end;
                 if (go && r < 32) {  // a run cut at 32 may simply go on
                     int s;
                     if (khg_cur_decode(cur, bits, sh.lut, lut2, left, right, tsym, &s) == 0) {
@@ -1285,7 +1293,7 @@ KHG_DEV void khg_dec_write_body(const KhgDecArgs& a, uint32_t blk, KhgDecWriteSm
                     } else {
                         q[i] = (int16_t)s;
                         ++i;
-                        go = i < todo;
+                        go = i < todo && cur.pos < sub_end;
                     }
                 }
             }

@@ -84,6 +84,38 @@ def test_an_index_that_lies_cannot_reach_outside_the_buffers():
         assert rc in (0, -3, -4)  # sound, malformed, or tables the decoder's limits refuse
 
 
+def test_forged_counts_in_a_stream_of_several_workgroups_stay_inside_the_staged_span():
+    """The index's first[] entries become the per-subsequence codeword counts of the write kernel.  Entries that
+    are not monotone, or inflated, must neither send a thread's cursor beyond the 256 subsequences its workgroup
+    staged nor make it decode more than its own 256 bits (run under AddressSanitizer by tools/asan_sim.sh: the
+    simulator's staging array has no slack).  Noise at the Normal preset: streams of several workgroup spans."""
+    rng = np.random.default_rng(11)
+    rgb = rng.integers(0, 256, (3, 256, 256), dtype=np.uint8)
+    v1 = O.encode(rgb, 0)
+    rc, v2 = S.encode_indexed(rgb, 0)
+    assert rc == 0 and v2[:len(v1)] == v1
+    hdr = np.frombuffer(v1[:12], dtype="<i4")
+    assert hdr[0] > 3 * 65536  # the luma stream spans more than three workgroups
+    start = (len(v1) + 7) // 8 * 8
+    head = np.frombuffer(v2[start:start + 72], dtype="<u4")
+    ne = int(head[15] + head[16] + head[17])  # entries of the three planes: a raster index (u32) and an offset (u8) each
+    first, offs = start + 72, start + 72 + 4 * ne
+    for rep in range(30):
+        bad = bytearray(v2)
+        kind = rep % 3
+        for _ in range(int(rng.integers(1, 40))):
+            e = int(rng.integers(0, ne))
+            if kind == 0:    # a raster index far too large, or one that steps backwards
+                bad[first + 4 * e:first + 4 * e + 4] = int(rng.integers(0, 1 << 32)).to_bytes(4, "little")
+            elif kind == 1:  # a stretch of entries that claim symbol 0: counts of zero, then a jump
+                for k in range(e, min(ne, e + 8)):
+                    bad[first + 4 * k:first + 4 * k + 4] = (0).to_bytes(4, "little")
+            else:            # an offset that points anywhere into the subsequence
+                bad[offs + e] = int(rng.integers(0, 256))
+        rc, out = S.decode_indexed(bytes(bad), 256, 256)
+        assert rc in (0, -3, -4)
+
+
 # ------------------------------------------------------------------ on the GPU, through the C ABI
 def _gpu_encode_indexed(codec, rgb, lvl):
     import torch
