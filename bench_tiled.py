@@ -35,6 +35,9 @@ def main():
     ap.add_argument("--virtual", type=int, default=0, help="rehearse this many ranks on one GPU (threads)")
     ap.add_argument("--merge", choices=("reduce", "gather"), default="reduce",
                     help="how the ranks' shares become the file (khugle_amd.tiled.encode_tiled)")
+    ap.add_argument("--host", choices=("native", "python"), default="native",
+                    help="native: the library's C++ host calls RCCL itself (khg_tile_encode / khg_tile_decode); "
+                         "python: the same schedule from khugle_amd.tiled over torch.distributed")
     ap.add_argument("--gpus", type=int, default=0,
                     help="ranks (one process per GPU); started plainly, this process launches them itself")
     args = ap.parse_args()
@@ -55,11 +58,17 @@ def main():
     side = args.side
     px = side * side
 
-    def run_rank(r, w, coll, codec):
+    def run_rank(r, w, coll, codec, comm=None):
         """Generate the tile, then warm-up + timed steps; returns (seconds, comp bytes tensor or None, tile)."""
         i0, i1 = tiled.input_rows(side, r, w)
         strip = codec.synth_rows_dev(i0, i1 - i0, side, SEED, 0)
         be = tiled.HipTileBackend(codec)
+        if comm is not None:
+            encode = lambda: tiled.encode_tiled_native(codec, comm, strip, side, side, LVL, merge=args.merge)
+            decode = lambda full, n: tiled.decode_tiled_native(codec, comm, full, n, side, side)
+        else:
+            encode = lambda: tiled.encode_tiled(be, strip, side, side, LVL, r, w, coll=coll, merge=args.merge)
+            decode = lambda full, n: tiled.decode_tiled(be, full, n, side, side, r, w, coll=coll)
         torch.cuda.synchronize()
         comp = tile = None
         length = torch.zeros(1, dtype=torch.int64, device=dev)
@@ -71,7 +80,7 @@ def main():
                 dist.barrier()
             torch.cuda.synchronize()
             a = time.perf_counter()
-            comp = tiled.encode_tiled(be, strip, side, side, LVL, r, w, coll=coll, merge=args.merge)
+            comp = encode()
             torch.cuda.synchronize()
             b = time.perf_counter()
             # the file goes back to every rank (decode needs the whole stream)
@@ -92,7 +101,7 @@ def main():
                 full[:n] = comp
             torch.cuda.synchronize()
             c = time.perf_counter()
-            tile = tiled.decode_tiled(be, full, n, side, side, r, w, coll=coll)
+            tile = decode(full, n)
             torch.cuda.synchronize()
             d = time.perf_counter()
             if it >= args.warmup:
@@ -123,7 +132,11 @@ def main():
                 bar.wait()
                 return out
 
-        res = run_ranks(w, lambda r, coll: run_rank(r, w, Coll(coll.sh, r), ctxs[r]))
+        comms = [None] * w
+        if args.host == "native":
+            group = tiled.Comm.local_group(w)
+            comms = [tiled.Comm.local(group, r, w) for r in range(w)]
+        res = run_ranks(w, lambda r, coll: run_rank(r, w, Coll(coll.sh, r), ctxs[r], comms[r]))
         t_enc = max(x[0] for x in res)
         t_dec = max(x[1] for x in res)
         comp = res[0][2]
@@ -143,7 +156,8 @@ def main():
         comp_len = comp.numel()
     else:
         codec = Codec(side, side, device=local_rank)
-        t_enc, t_dec, comp, tile = run_rank(rank, world, None, codec)
+        comm = tiled.Comm.rccl(rank, world, local_rank) if args.host == "native" else None
+        t_enc, t_dec, comp, tile = run_rank(rank, world, None, codec, comm)
         tt = torch.tensor([t_enc, t_dec], dtype=torch.float64, device=dev)
         if world > 1:
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -160,7 +174,7 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "encode_mp_s": round(mp / t_enc, 1),
             "decode_mp_s": round(mp / t_dec, 1), "comp_bytes": comp_len,
             "bits_per_pixel": round(8.0 * comp_len / px, 4), "identical_to_single_tile": ok, "merge": args.merge,
-            "scaling": "strong", "data": "synthetic", "dtype": "f64"}), flush=True)
+            "host": args.host, "scaling": "strong", "data": "synthetic", "dtype": "f64"}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

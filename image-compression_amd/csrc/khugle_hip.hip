@@ -783,5 +783,6 @@ extern "C" int khg_synth_rows_dev(uint8_t* d_r, uint8_t* d_g, uint8_t* d_b, int 
 
 #include "khg_host_decode.inl"
 #include "khg_host_tile.inl"
+#include "khg_host_comm.inl"
 #include "khg_host_batch.inl"
 #include "khg_host_visual.inl"

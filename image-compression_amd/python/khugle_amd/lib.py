@@ -87,6 +87,16 @@ SYMBOLS = [
     ("khg_tile_sym_get", C.c_int, [_P, C.c_int, C.c_uint32, C.c_uint32, _P, _P]),
     ("khg_tile_sym_set", C.c_int, [_P, C.c_int, C.c_uint32, C.c_uint32, _P, _P]),
     ("khg_tile_decode_inverse_dev", C.c_int, [_P, _P, _P, _P, _P]),
+    ("khg_comm_unique_id", C.c_int, [_P, C.c_size_t]),
+    ("khg_comm_create_rccl", C.c_int, [C.POINTER(_P), C.c_int, C.c_int, _P, C.c_size_t, C.c_int]),
+    ("khg_comm_wrap_rccl", C.c_int, [C.POINTER(_P), _P, C.c_int, C.c_int]),
+    ("khg_comm_local_group", _P, [C.c_int]),
+    ("khg_comm_create_local", C.c_int, [C.POINTER(_P), _P, C.c_int]),
+    ("khg_comm_destroy", None, [_P]),
+    ("khg_tile_exchange_halos", C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P]),
+    ("khg_tile_encode", C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_size_t,
+                                  C.POINTER(C.c_size_t), C.c_int, C.c_int, _P]),
+    ("khg_tile_decode", C.c_int, [_P, _P, _P, C.c_size_t, C.c_int, C.c_int, _P, _P, _P, _P]),
     ("khg_profile_luma_forward", C.c_int, [_P, C.c_int]),
     ("khg_profile_read", C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     ("khg_ssim_dev", C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.POINTER(C.c_double), _P]),

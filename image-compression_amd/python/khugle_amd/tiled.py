@@ -10,8 +10,11 @@ Rank t of n owns image rows [rows*t/n, rows*(t+1)/n).  Data movement between ran
   * decode         : the entropy decode is split over the ranks (each decodes 1/n of every plane's stream):
                      all-reduce SUM of the workgroup records -> every rank chains all spans; then decoded symbols
                      go point to point from the ranks that hold them to the ranks whose rows need them
-On GPUs the process group is RCCL (backend "nccl"); the CPU tests run the same code over gloo with the kernel
-simulator behind the same backend interface.
+Two hosts run this schedule.  The library's own (khg_tile_encode / khg_tile_decode on a khg_comm: RCCL called from
+C++, every exchange in place on the context's buffers) is what Comm / encode_tiled_native / decode_tiled_native
+below call: the path for GPUs.  encode_tiled / decode_tiled run the same steps from Python over a torch.distributed
+process group; with gloo and the kernel simulator behind the same backend interface they are how the CPU tests
+cover the schedule, and on GPUs (backend "nccl") they serve as the cross-check of the native host.
 """
 import ctypes as C
 
@@ -357,4 +360,82 @@ def decode_tiled(backend, comp, length, rows, cols, rank, world, coll=None, spli
     worst = int(st.item())
     if worst != 0:
         raise _lib.KhgError(worst, "decode_tiled (rank %d saw status %d)" % (rank, status))
+    return out
+
+
+# ---- the library's own host for the tiled mode
+
+UNIQUE_ID_BYTES = 128
+
+
+class Comm:
+    """A khg_comm.  Comm.rccl(rank, world, device, group): every rank of the torch.distributed group calls it; the
+    group only carries rank 0's RCCL id to the others (any backend).  Comm.local_group(n) / Comm.local(group, rank):
+    ranks that are threads of this process on one GPU."""
+
+    def __init__(self, handle, rank, world):
+        self._h, self.rank, self.world = handle, rank, world
+
+    @classmethod
+    def rccl(cls, rank, world, device, group=None):
+        L = _lib.load()
+        ident = torch.zeros(UNIQUE_ID_BYTES, dtype=torch.uint8)
+        if rank == 0:
+            _check(L.khg_comm_unique_id(C.c_void_p(ident.data_ptr()), UNIQUE_ID_BYTES), "comm_unique_id")
+        if world > 1:
+            box = [ident.numpy().tobytes()]
+            dist.broadcast_object_list(box, src=0, group=group)
+            ident = torch.frombuffer(bytearray(box[0]), dtype=torch.uint8)
+        h = C.c_void_p()
+        _check(L.khg_comm_create_rccl(C.byref(h), rank, world, C.c_void_p(ident.data_ptr()), UNIQUE_ID_BYTES, device),
+               "comm_create_rccl")
+        return cls(h, rank, world)
+
+    @staticmethod
+    def local_group(world):
+        g = _lib.load().khg_comm_local_group(world)
+        if not g:
+            raise ValueError("a local group has 1 to 8 ranks")
+        return g
+
+    @classmethod
+    def local(cls, group, rank, world):
+        h = C.c_void_p()
+        _check(_lib.load().khg_comm_create_local(C.byref(h), group, rank), "comm_create_local")
+        return cls(h, rank, world)
+
+    def close(self):
+        if self._h:
+            _lib.load().khg_comm_destroy(self._h)
+            self._h = None
+
+
+def exchange_halos_native(codec, comm, own, rows):
+    """own: (3, rows/world, cols) uint8 device tensor -> the strip encode_tiled_native takes."""
+    _, R, W = own.shape
+    i0, i1 = input_rows(rows, comm.rank, comm.world)
+    strip = torch.empty((3, i1 - i0, W), dtype=torch.uint8, device=own.device)
+    _check(codec.L.khg_tile_exchange_halos(comm._h, _ptr(own[0]), _ptr(own[1]), _ptr(own[2]), rows, W, _ptr(strip[0]),
+                                           _ptr(strip[1]), _ptr(strip[2]), _stream()), "tile_exchange_halos")
+    return strip
+
+
+def encode_tiled_native(codec, comm, strip, rows, cols, lvl, dst=0, merge="reduce"):
+    """encode_tiled on the library's host: returns the file's bytes (uint8 device tensor) on rank dst, None elsewhere."""
+    assert strip.is_cuda and strip.dtype == torch.uint8 and strip.is_contiguous()
+    cap = int(codec.L.khg_comp_bound(rows, cols))
+    out = torch.empty(cap, dtype=torch.uint8, device=strip.device)
+    n = C.c_size_t(0)
+    _check(codec.L.khg_tile_encode(codec._ctx, comm._h, _ptr(strip[0]), _ptr(strip[1]), _ptr(strip[2]), rows, cols, lvl,
+                                   _ptr(out), cap, C.byref(n), dst, {"reduce": 0, "gather": 1}[merge], _stream()),
+           "tile_encode")
+    return out[: n.value] if comm.rank == dst else None
+
+
+def decode_tiled_native(codec, comm, comp, length, rows, cols):
+    """decode_tiled (split entropy decode) on the library's host: the rank's rows, (3, rows/world, cols) uint8."""
+    r0, r1 = tile_rows(rows, comm.rank, comm.world)
+    out = torch.empty((3, r1 - r0, cols), dtype=torch.uint8, device=comp.device)
+    _check(codec.L.khg_tile_decode(codec._ctx, comm._h, _ptr(comp), length, rows, cols, _ptr(out[0]), _ptr(out[1]),
+                                   _ptr(out[2]), _stream()), "tile_decode")
     return out

@@ -274,6 +274,50 @@ int khg_tile_sym_get(khg_ctx *ctx, int plane, uint32_t first, uint32_t count, in
 int khg_tile_sym_set(khg_ctx *ctx, int plane, uint32_t first, uint32_t count, const int16_t *d_src, void *stream);
 int khg_tile_decode_inverse_dev(khg_ctx *ctx, uint8_t *d_r, uint8_t *d_g, uint8_t *d_b, void *stream);
 
+/* ---- the tiled mode with its collectives inside the library (no counterpart in the reference, whose single
+ * CompressImage / decompress calls, Compress.h:104 and Decompress.h:274, these replace for an image spread over
+ * several GPUs).  khg_tile_encode and khg_tile_decode run the steps above and, between them, the exchanges -- the
+ * all-reduces of the histogram, the chunk bit counts, the workgroup records and the status, the merge of the output
+ * bytes, the point-to-point moves of halo rows and decoded symbols -- in place on the context's own buffers, on a
+ * communicator:
+ *   khg_comm_create_rccl   RCCL, one process per GPU: rank 0 calls khg_comm_unique_id (128 bytes), hands the id to
+ *                          the other ranks by whatever means the application has, and every rank creates its
+ *                          communicator from it (a collective call).  khg_comm_wrap_rccl takes an ncclComm_t the
+ *                          application already owns.  RCCL is looked up at run time (the copy the process holds,
+ *                          else librccl.so.1): KHG_ERR_HIP if there is none.
+ *   khg_comm_create_local  the ranks are threads of one process with their contexts on one GPU
+ *                          (khg_comm_local_group(n) makes the group, each thread joins as one rank): the same host
+ *                          code with device-to-device copies in place of the links -- for rehearsals and tests.
+ * At most 8 ranks.  All ranks call each function together, with the same rows / cols / lvl / root / merge, and
+ * contexts of the same capacity.  Both functions wait for the stream.  A failure that one rank's checks or kernels
+ * find (bad argument, busy context, symbol out of range, output too small, damaged stream) is returned by every
+ * rank -- the one that found it returns its own code, the others the lowest code any rank had; KHG_ERR_HIP (also
+ * for RCCL errors) is returned at once and leaves the communicator unusable.
+ *   khg_tile_exchange_halos  d_own_*: the rank's rows/n image rows (rows/n >= 24); d_strip_*: receives image rows
+ *                          khg_tile_input_rows -- the rank's rows with its neighbours' 24 edge rows attached.
+ *   khg_tile_encode        d_r/d_g/d_b: that strip.  The file -- the bytes one encoder produces -- arrives in d_out
+ *                          on rank `root` (on other ranks d_out is scratch of the same capacity, khg_comp_bound);
+ *                          *out_len on every rank.  merge 0: one reduce of the file's size adds the ranks' zero-padded
+ *                          shares; merge 1: every byte moves once, point to point (a kernel on each rank works out
+ *                          which 32-bit words its chunks touch and packs them; the keeper adds them in place).
+ *   khg_tile_decode        d_comp: the whole file on every rank; d_r/d_g/d_b receive the rank's rows.  The entropy
+ *                          decode is split over the ranks; decoded symbols go straight from the symbol planes of the
+ *                          ranks that hold them into those of the ranks whose rows need them. */
+typedef struct khg_comm khg_comm;
+int khg_comm_unique_id(void *id, size_t bytes);
+int khg_comm_create_rccl(khg_comm **out, int rank, int nranks, const void *id, size_t bytes, int device);
+int khg_comm_wrap_rccl(khg_comm **out, void *nccl_comm, int rank, int nranks);
+void *khg_comm_local_group(int nranks);
+int khg_comm_create_local(khg_comm **out, void *group, int rank);
+void khg_comm_destroy(khg_comm *comm);
+int khg_tile_exchange_halos(khg_comm *comm, const uint8_t *d_own_r, const uint8_t *d_own_g, const uint8_t *d_own_b,
+                            int rows, int cols, uint8_t *d_strip_r, uint8_t *d_strip_g, uint8_t *d_strip_b,
+                            void *stream);
+int khg_tile_encode(khg_ctx *ctx, khg_comm *comm, const uint8_t *d_r, const uint8_t *d_g, const uint8_t *d_b, int rows,
+                    int cols, int lvl, uint8_t *d_out, size_t cap, size_t *out_len, int root, int merge, void *stream);
+int khg_tile_decode(khg_ctx *ctx, khg_comm *comm, const uint8_t *d_comp, size_t len, int rows, int cols, uint8_t *d_r,
+                    uint8_t *d_g, uint8_t *d_b, void *stream);
+
 /* Measurement aid: while enabled, khg_encode_dev brackets its luma level-1 forward launch with HIP events on
  * the caller's stream, and the kernel notes the device clock at which its first workgroup starts and its last
  * one ends; khg_encode_result adds both durations to per-context tallies that khg_profile_read returns

@@ -15,6 +15,7 @@ IMAGES = ["baboon", "bird", "camera", "cat", "couple", "girl", "house", "lena", 
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a HIP device (run on the MI355X box)")
+    config.addinivalue_line("markers", "slow: a GPU test of tens of seconds (the largest configuration at its size)")
 
 
 @pytest.fixture(scope="session")
