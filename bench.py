@@ -27,6 +27,8 @@ for _p in (os.path.join(ROOT, "image-compression_amd", "python"), os.path.join(R
 
 ROWS, COLS, LVL, SEED = 4320, 7680, 1, 2025
 HBM_PEAK_GBS = 8000.0
+CPU_POOL_CAP = 16  # CPUs a one-GPU job may use on the GPU boxes
+PROFILE_TAG = "r03"  # profiles/<tag>_kernels.json, profiles/<tag>_valu.json
 # Level-1 forward launch (colour + DWT level 1 + quantiser + histogram of Y, Cb and Cr in one kernel, the longest
 # data-parallel kernel of the path), algorithmic bytes per luma pixel:
 #   3     u8 R, G, B read once
@@ -77,8 +79,12 @@ def _cpu_worker(args):
 def cpu_baseline(side=5760, frames_per_core=1):
     import multiprocessing as mp
     import oracle_py as O
-    cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
-    cores = max(1, min(cores, 16))
+    # One process per core of this job's CPU share.  os.cpu_count() reports the whole machine; the GPU boxes give a
+    # one-GPU job 16 CPUs and export that figure as OMP_NUM_THREADS, so the pool is capped there (CPU_POOL_CAP when
+    # the variable is absent).
+    host_cores = os.cpu_count() or 1
+    share = int(os.environ.get("OMP_NUM_THREADS", "0")) or CPU_POOL_CAP
+    cores = max(1, min(host_cores, share))
     O.build()
     kind = "reference" if O.have_ref() else "port"
     jobs = [(side, SEED, i * frames_per_core, frames_per_core, LVL) for i in range(cores)]
@@ -93,6 +99,8 @@ def cpu_baseline(side=5760, frames_per_core=1):
     what = ("reference DWT.h/Huffman.h/Writer.h/Reader.h compiled as they are + restated colour/quantiser"
             if kind == "reference" else "CPU restatement with the reference's O(N*K) table search")
     return {"value": round(mp_total / busy, 3), "unit": "MP/s encode+decode", "cores": cores, "kind": kind,
+            "host_cores": host_cores,
+            "cores_note": "pool = min(os.cpu_count() = %d, this job's CPU share = %d)" % (host_cores, share),
             "frames_timed": cores * frames_per_core,
             "sample": "%d frames of %dx%d (same generator, seed %d, High preset; the reference cannot "
                       "round-trip non-square frames), one process per core, %s; per core: encode %.2f MP/s, "
@@ -111,6 +119,7 @@ def main():
     ap.add_argument("--cols", type=int, default=COLS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-square", action="store_true", help="skip the short 5760x5760 pass")
+    ap.add_argument("--no-presets", action="store_true", help="skip the short Normal / Extreme passes")
     ap.add_argument("--no-format2", action="store_true", help="skip the short pass with the opt-in seek index")
     ap.add_argument("--no-host-pipeline", action="store_true", help="skip the short pass over frames in host memory")
     ap.add_argument("--no-isolated-kernel", action="store_true",
@@ -263,10 +272,62 @@ def main():
                   "value": round(whole_job_rate(world, SF, 1, side * side, st), 1), "unit": "MP/s"}
         del sctx, sfr, scomp, sdec
 
+    dec_last = decs[(F - 1) % S].clone()  # the timed decode's picture of the last frame, for the parity spot check
+    # the other two presets of the reference (Compress.h:19-41), one pass each way over the first frames: Normal
+    # quantises least, so its tables are the largest (the tree kernels' time grows with the table) and its files the
+    # longest.  Never part of `value`: the headline configuration is High.
+    presets = None
+    if not args.no_presets:
+        PF = min(F, 48)
+        presets = {}
+        for name, lvl in (("Normal", 0), ("Extreme", 2)):
+            plen = [0] * PF
+
+            def enc_p():
+                for f in range(PF):
+                    c = f % S
+                    if f >= S:
+                        plen[f - S] = ctxs[c].encode_result()
+                    with torch.cuda.stream(streams[c]):
+                        ctxs[c].encode_dev(frames[f], lvl, comps[f])
+                for f in range(max(0, PF - S), PF):
+                    plen[f] = ctxs[f % S].encode_result()
+
+            def dec_p():
+                for f in range(PF):
+                    c = f % S
+                    if f >= S and ctxs[c].last_status() != 0:
+                        raise RuntimeError("decode failed (preset %s)" % name)
+                    with torch.cuda.stream(streams[c]):
+                        ctxs[c].decode_dev(comps[f], plen[f], rows, cols, decs[c])
+                for c in range(min(S, PF)):
+                    if ctxs[c].last_status() != 0:
+                        raise RuntimeError("decode failed (preset %s)" % name)
+
+            enc_p(); dec_p()
+            barrier()
+            pa = time.perf_counter()
+            enc_p()
+            torch.cuda.synchronize()
+            pb = time.perf_counter()
+            dec_p()
+            torch.cuda.synchronize()
+            pc = time.perf_counter()
+            barrier()
+            pe, pd = max_over_ranks([pb - pa, pc - pb], dev)
+            hd = khugle_amd.peek(comps[0, :plen[0]].cpu().numpy().tobytes())
+            presets[name] = {"value": round(whole_job_rate(world, PF, 1, px, pe + pd), 1), "unit": "MP/s",
+                             "encode_mp_s": round(whole_job_rate(world, PF, 1, px, pe), 1),
+                             "decode_mp_s": round(whole_job_rate(world, PF, 1, px, pd), 1),
+                             "bits_per_pixel": round(8.0 * sum(plen) / (PF * px), 4),
+                             "table_entries": [hd.rle_y_len, hd.rle_cb_len, hd.rle_cr_len],
+                             "frames_per_gpu": PF}
+        # the timed frames are re-encoded below (format 2 or not), so comps and lens stay those of the High preset
+        encode_pass()
+
     # the same frames in the opt-in format 2 (the format-1 file followed by a seek index, csrc/khg_index.h): one pass
     # each way.  Never part of `value`: the headline is the reference's own format.
     format2 = None
-    dec_last = decs[(F - 1) % S].clone()  # the timed decode's picture of the last frame, for the parity spot check
     if not args.no_format2:
         lens2 = [0] * F
 
@@ -363,13 +424,35 @@ def main():
             parity = "unavailable: %s" % e
         # HBM bytes per launch from the counters and the per-kernel table: collected by tools/gpu_roofline.sh
         # (rocprofv3 --kernel-trace --stats and one --pmc pass each for FETCH_SIZE and WRITE_SIZE), committed
-        traffic = per_kernel = None
-        tpath = os.path.join(ROOT, "profiles", "r02_kernels.json")
+        traffic = per_kernel = profile_head = valu = None
+        stale = None
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from source_stamp import csrc_digest
+        running = csrc_digest()
+        tpath = os.path.join(ROOT, "profiles", PROFILE_TAG + "_kernels.json")
         if os.path.exists(tpath):
             prof_table = json.load(open(tpath))
             traffic = prof_table["kernels"].get("khg_fwd_kernel<0>", {}).get("traffic_bytes")
             per_kernel = {k: {f: v[f] for f in ("avg_us", "algorithmic_bytes", "traffic_bytes", "frac") if f in v}
                           for k, v in prof_table["kernels"].items()}
+            at = prof_table.get("taken_at", {})
+            profile_head = at.get("git_head")
+            stale = at.get("csrc_sha256") != running
+        vpath = os.path.join(ROOT, "profiles", PROFILE_TAG + "_valu.json")
+        if os.path.exists(vpath):
+            v = json.load(open(vpath))
+            valu = {"wave_insts": v["valu_wave_insts"],
+                    "cycles_per_f64_wave_inst_per_simd": v["f64_probe"]["cycles_per_wave_inst_per_simd"],
+                    "ns_per_f64_wave_inst_per_simd": v["f64_probe"]["ns_per_wave_inst_per_simd"],
+                    "shader_ghz_held_in_probe": v["f64_probe"]["shader_ghz_held"],
+                    "shader_ghz_held_in_kernel": v["shader_ghz_held_in_kernel"],
+                    "ceiling_us": v["ceiling_us"], "profiled_launch_us": v["launch_us"], "frac": v["frac"],
+                    "gap_to_1p67_ns": v["gap"],
+                    "profile_head": v.get("taken_at", {}).get("git_head"),
+                    "stale": v.get("taken_at", {}).get("csrc_sha256") != running,
+                    "source": "profiles/%s_valu.json (tools/gpu_valu.sh: tools/probe_rates.hip with s_memtime against "
+                              "s_memrealtime, a KHG_TIMING build for the clock inside the launch, SQ_INSTS_VALU from "
+                              "a --pmc pass)" % PROFILE_TAG}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline()
@@ -386,7 +469,8 @@ def main():
         # workgroups wait for CUs held by other frames' kernels -- a lower bound on the kernel's rate, not its cost.
         main = priced(k_alone_ms) if k_alone_ms is not None else priced(k_ms)
         roofline = {"bound": "hbm",
-                    "kernel": "khg_fwd_kernel<0> (colour + DWT level 1 + quantiser + histogram of Y, Cb, Cr)",
+                    "kernel": "khg_fwd_kernel<0, 2, 1, false> (colour + DWT level 1 + quantiser + histogram of Y, Cb, "
+                              "Cr; khg_fwd_kernel<0> in the tables)",
                     "achieved": main["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": main["frac"],
                     "traffic": traffic, "bytes_per_launch": l1_bytes, "avg_launch_ms": main["avg_launch_ms"],
                     "timing": ("20 launches on an idle GPU after the timed region, HIP events on the launch stream"
@@ -400,10 +484,15 @@ def main():
                                      "note": "what the stages fused into this launch would move as separate passes "
                                              "with f64 planes between them; the launch is priced at its compulsory "
                                              "8.25 B/px"},
+                    "valu": valu,
                     "per_kernel_profile": per_kernel,
-                    "per_kernel_profile_note": "one-stream 8K frame under rocprofv3 (profiles/r02_kernels.json, made by "
+                    "per_kernel_profile_head": profile_head,
+                    "stale": stale,
+                    "per_kernel_profile_note": "one-stream 8K frame under rocprofv3 (profiles/%s_kernels.json, made by "
                                                "tools/gpu_roofline.sh): avg_us, algorithmic and counter bytes per "
-                                               "launch, fraction of the 8 TB/s HBM peak"}
+                                               "launch, fraction of the 8 TB/s HBM peak; stale = the library's "
+                                               "sources have changed since (digest over csrc/ and the public "
+                                               "header)" % PROFILE_TAG}
         total_mp = world * F * args.steps * px / 1e6
         bpp = 8.0 * sum(lens) / (F * px)
         line = {
@@ -434,6 +523,7 @@ def main():
                                "encode_gbps": round((63 + bpp / 8) * total_mp / t_enc / 1e3, 1),
                                "decode_gbps": round((63 + bpp / 8) * total_mp / t_dec / 1e3, 1),
                                "peak_gbps": HBM_PEAK_GBS * world},
+            "presets": presets,
             "square_variant": square,
             "format2": format2,
             "host_pipeline": host,

@@ -34,12 +34,18 @@ def model(px, comp):
 
 
 def short(name):
-    n = name.replace("void ", "")
-    return n.split("(")[0]
+    """khg_fwd_kernel<0, 2, 1, false>(KhgFwdArgs) -> khg_fwd_kernel<0>: the first template argument says which
+    launch it is (level, source); the others are tuning variants of the same launch."""
+    n = name.replace("void ", "").split("(")[0]
+    if n.startswith("khg_fwd_kernel<") and "," in n:
+        n = n.split(",")[0] + ">"
+    return n
 
 
 def main():
     stats, fetch, write, comp, out = sys.argv[1:6]
+    sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.abspath(__file__)))
+    from source_stamp import stamp
     px = 4320 * 7680
     dur = {}
     for r in csv.DictReader(open(stats)):
@@ -73,7 +79,8 @@ def main():
         else:
             row["what"] = "latency class (one or a few workgroups): not priced against HBM"
         table[k] = row
-    json.dump({"frame": "7680x4320 synthetic, High preset, one stream", "comp_bytes": int(comp), "peak_gbps": PEAK,
+    json.dump({"taken_at": stamp(),
+               "frame": "7680x4320 synthetic, High preset, one stream", "comp_bytes": int(comp), "peak_gbps": PEAK,
                "counter_note": "fetch_bytes = 2 x FETCH_SIZE x 1024 (gfx950 correction), write_bytes = WRITE_SIZE x 1024, "
                                "each from its own rocprofv3 --pmc pass",
                "kernels": table}, open(out, "w"), indent=1)
