@@ -274,6 +274,32 @@ enum { KHG_SSIM_STATIC_BLOCKS = (7680 / 8) * (4320 / 8), KHG_MAX_DEVICES = 64 };
 static __device__ __align__(256) double khg_ssim_scratch[KHG_SSIM_STATIC_BLOCKS];
 static double* g_ssim_scratch_ptr[KHG_MAX_DEVICES];  // device address of the array on each device, once looked up
 
+// The array's address on the current device (each device holds its own copy at its own address), looked up once.
+static int khg_ssim_scratch_of_current_device(int* dev_out, double** scratch)
+{
+    int dev = -1;
+    KHG_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= KHG_MAX_DEVICES) return KHG_ERR_HIP;
+    double* sc = __atomic_load_n(&g_ssim_scratch_ptr[dev], __ATOMIC_ACQUIRE);
+    if (!sc) {
+        void* p = nullptr;
+        KHG_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(khg_ssim_scratch)));
+        if (!p) return KHG_ERR_HIP;
+        sc = (double*)p;
+        __atomic_store_n(&g_ssim_scratch_ptr[dev], sc, __ATOMIC_RELEASE);
+    }
+    *dev_out = dev;
+    *scratch = sc;
+    return KHG_OK;
+}
+
+extern "C" int khg_ssim_static_prepare(void)
+{
+    int dev;
+    double* scratch;
+    return khg_ssim_scratch_of_current_device(&dev, &scratch);
+}
+
 extern "C" int khg_ssim_static_dev(const uint8_t* d_a, const uint8_t* d_b, int width, int height, double* d_ssim,
                                    void* stream)
 {
@@ -281,15 +307,13 @@ extern "C" int khg_ssim_static_dev(const uint8_t* d_a, const uint8_t* d_b, int w
     if (width < 8 || height < 8) return KHG_ERR_DIMS;
     if ((size_t)(width / 8) * (size_t)(height / 8) > (size_t)KHG_SSIM_STATIC_BLOCKS) return KHG_ERR_DIMS;  // beyond the fixed array
     int dev = -1;
-    KHG_HIP(hipGetDevice(&dev));
-    if (dev < 0 || dev >= KHG_MAX_DEVICES) return KHG_ERR_HIP;
-    double* scratch = __atomic_load_n(&g_ssim_scratch_ptr[dev], __ATOMIC_ACQUIRE);
-    if (!scratch) {  // first call on this device: each device holds its own copy of the array at its own address
-        void* p = nullptr;
-        KHG_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(khg_ssim_scratch)));
-        if (!p) return KHG_ERR_HIP;
-        scratch = (double*)p;
-        __atomic_store_n(&g_ssim_scratch_ptr[dev], scratch, __ATOMIC_RELEASE);
+    double* scratch = nullptr;
+    int rc = khg_ssim_scratch_of_current_device(&dev, &scratch);
+    if (rc) return rc;
+    if (stream) {  // the array used is the current device's: a stream of another device would write through a foreign address
+        int sdev = -1;
+        KHG_HIP(hipStreamGetDevice((hipStream_t)stream, &sdev));
+        if (sdev != dev) return KHG_ERR_ARG;
     }
     return khg_ssim_enqueue(d_a, d_b, width, height, scratch, d_ssim, (hipStream_t)stream);
 }

@@ -4,8 +4,9 @@
 // Format 2 keeps the file of format 1 byte for byte and appends what those two kernels would work out: for every
 // KHG_SUB_BITS bits of each stream, where the first codeword that starts in them lies and which symbol it is.  A
 // reader of format 1 (the reference's ReadAll) stops before the index and never sees it; the indexed decoder skips the
-// two kernels.  The index also carries what the 36-byte header cannot: both dimensions as they are, and 64-bit stream
-// lengths.  It has no counterpart in the reference.
+// two kernels.  The index also carries both dimensions as they are, and stream lengths in fields 64 bits wide -- room
+// for streams beyond the 36-byte header's int lengths (Type.h:5), which this encoder and decoder do not produce or
+// accept: the high words are written as zero and anything else is refused.  It has no counterpart in the reference.
 //
 // Layout, little-endian 32-bit words unless noted, from the first multiple of 8 at or behind the end of the format-1
 // file (the gap holds zeros):

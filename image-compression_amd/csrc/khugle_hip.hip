@@ -299,6 +299,8 @@ struct khg_ctx {
     hipStream_t last_stream;
     int used;            // `done` has been recorded at least once
     int pending;         // an encode/decode was enqueued and its result not yet fetched
+    int open;            // khg_begin was called and khg_end was not (yet, or ever: an entry point that failed midway)
+    hipStream_t open_stream;
     // lazily allocated staging for the host-pointer entry points
     uint8_t* stage_rgb;  // 3 planes
     uint8_t* stage_comp;
@@ -439,10 +441,21 @@ static int khg_check_image(const khg_ctx* c, int rows, int cols)
 //     is refused (KHG_ERR_BUSY): it would overwrite the result block and its pinned host copy;
 //   - work enqueued on another stream than the context's previous work waits (on the device) for that work's
 //     completion event, so a change of stream cannot let two jobs run side by side in one workspace.
+//   - an entry point that fails between the two calls (a launch error, a refused argument found late) leaves the
+//     job open: kernels it did launch have no completion event.  The next khg_begin sees that, waits for the stream
+//     the open job was on, and starts from a clean slate (no pending result, no tiled decode in progress).
 static int khg_begin(khg_ctx* c, hipStream_t st)
 {
+    if (c->open) {
+        KHG_HIP(hipStreamSynchronize(c->open_stream));
+        c->open = 0;
+        c->pending = 0;
+        c->tdec_step = 0;
+    }
     if (c->pending) return KHG_ERR_BUSY;
     if (c->used && st != c->last_stream) KHG_HIP(hipStreamWaitEvent(st, c->done, 0));
+    c->open = 1;
+    c->open_stream = st;
     return KHG_OK;
 }
 
@@ -452,6 +465,7 @@ static int khg_end(khg_ctx* c, hipStream_t st, int pending)
     c->last_stream = st;
     c->used = 1;
     c->pending = pending;
+    c->open = 0;
     return KHG_OK;
 }
 

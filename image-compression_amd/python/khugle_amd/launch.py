@@ -3,14 +3,22 @@
 A benchmark script calls ranks_or_spawn(n) first thing.  Under an external launcher (torch.distributed.run sets
 RANK / WORLD_SIZE) it only checks that the launcher's world size is the requested one.  Started plainly with
 n > 1 it becomes the parent: it starts n copies of the script, one per GPU, with RANK / LOCAL_RANK / WORLD_SIZE /
-MASTER_ADDR / MASTER_PORT set, waits for them and exits with the worst exit code.  The parent never touches the
-GPU (counting devices does not initialise HIP), so nothing is inherited by, or competes with, the ranks.
+MASTER_ADDR / MASTER_PORT set, waits for them and exits with the worst exit code.  The parent runs no GPU work.
+(Counting the devices may initialise the HIP runtime in the parent -- torch falls back to hipGetDeviceCount where
+it has no amdsmi -- which is harmless here: the ranks are fresh processes started with Popen, not forks that would
+inherit the runtime's state, and the parent never replaces itself with another program.)
+When a rank fails, the others are told to stop (SIGTERM); a rank that has not gone after KILL_AFTER seconds -- it may
+sit in a collective or a GPU wait that ignores the signal -- is killed, so the parent always exits.
 """
 import os
 import socket
 import subprocess
 import sys
 import time
+
+
+# seconds between SIGTERM and SIGKILL for the ranks that outlive a failed one
+KILL_AFTER = float(os.environ.get("KHG_LAUNCH_KILL_AFTER", "10"))
 
 
 def _free_port():
@@ -55,6 +63,7 @@ def ranks_or_spawn(n, need_devices=True, argv=None):
         procs.append(subprocess.Popen([sys.executable] + argv, env=env))
     worst = 0
     alive = list(procs)
+    kill_at = None
     while alive:
         time.sleep(0.05)
         for p in list(alive):
@@ -66,4 +75,9 @@ def ranks_or_spawn(n, need_devices=True, argv=None):
                 worst = rc if rc > 0 else 1
                 for q in alive:  # one rank failed: the others would wait in a collective for ever
                     q.terminate()
+                kill_at = time.monotonic() + KILL_AFTER
+        if kill_at is not None and alive and time.monotonic() >= kill_at:
+            for q in alive:
+                q.kill()
+            kill_at = None
     raise SystemExit(worst)

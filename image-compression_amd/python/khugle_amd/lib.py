@@ -101,6 +101,7 @@ SYMBOLS = [
     ("khg_profile_read", C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     ("khg_ssim_dev", C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.POINTER(C.c_double), _P]),
     ("khg_ssim_static_dev", C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P]),
+    ("khg_ssim_static_prepare", C.c_int, []),
     ("khg_psnr_dev", C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.POINTER(C.c_double), _P]),
     ("khg_forward_planes_dev", C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P]),
     ("khg_symbols_dev", C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P]),

@@ -269,39 +269,68 @@ def gather_shares(words, own, bits, off, rank, world, coll, dst):
     return out
 
 
+def _agreed(coll, device, rank, what, step):
+    """Runs step() and makes its failure every rank's failure.  A step that raises KhgError on one rank only (a busy
+    context, a launch that failed, no memory) must not leave the other ranks waiting in the next collective: the
+    ranks exchange the step's code (all-reduce MIN, codes are negative) and raise together.  Returns step()'s value."""
+    code, value = 0, None
+    try:
+        value = step()
+    except _lib.KhgError as e:
+        code = e.code
+    st = torch.tensor([code], dtype=torch.int32, device=device)
+    coll.all_reduce_min(st)
+    worst = int(st.item())
+    if worst != 0:
+        raise _lib.KhgError(worst, "%s (rank %d saw status %d)" % (what, rank, code))
+    return value
+
+
 def encode_tiled(backend, strip, rows, cols, lvl, rank, world, coll=None, dst=0, merge="reduce"):
     """All ranks call this with their strip (image rows input_rows(rows, rank, world)).  Returns the bytes of the
     .comp file as a uint8 tensor on rank `dst` (None elsewhere) -- the same bytes a single GPU produces.
     merge: "reduce" adds the ranks' whole zero-padded shares up in one collective of the file's size; "gather" moves
     every byte of the file once, point to point (gather_shares: an eighth of the link traffic on eight ranks, paid
-    for with index arithmetic on every rank)."""
+    for with index arithmetic on every rank).
+    Every group of steps between two collectives is agreed on (_agreed): a failure on any rank raises on all."""
     coll = coll or DistCollectives()
-    backend.forward(strip, rows, cols, lvl, rank, world)
-    cnt, first = backend.hist_get()
+    dev = strip.device
+
+    def first():
+        backend.forward(strip, rows, cols, lvl, rank, world)
+        return backend.hist_get()
+
+    cnt, first_idx = _agreed(coll, dev, rank, "encode_tiled: forward", first)
     # first raster indices: 0xFFFFFFFF (= -1 as int32) marks a symbol this tile never saw; raster indices stay
     # below 2^31 (checked by the library), so for the MIN reduce the mark becomes the largest int32
-    first = torch.where(first < 0, torch.full_like(first, _ABSENT), first)
+    first_idx = torch.where(first_idx < 0, torch.full_like(first_idx, _ABSENT), first_idx)
     coll.all_reduce_sum(cnt)
-    coll.all_reduce_min(first)
-    first = torch.where(first == _ABSENT, torch.full_like(first, -1), first)
-    backend.hist_set(cnt, first)
-    backend.lens()
-    bits = backend.bits_get()
+    coll.all_reduce_min(first_idx)
+    first_idx = torch.where(first_idx == _ABSENT, torch.full_like(first_idx, -1), first_idx)
+
+    def second():
+        backend.hist_set(cnt, first_idx)
+        backend.lens()
+        return backend.bits_get()
+
+    bits = _agreed(coll, dev, rank, "encode_tiled: code lengths", second)
     own = bits != 0  # before the all-reduce only this rank's chunks have a bit count
     coll.all_reduce_sum(bits)
-    backend.bits_set(bits)
-    share, total, status = backend.pack(backend.comp_bound(rows, cols))
-    # A failure (a symbol out of range, a stream of 2^31 bits) may show on one rank only.  The ranks agree on the
-    # status before the byte reduce, so that all of them raise together instead of one raising and the others
-    # waiting in the reduce for ever.
-    st = torch.tensor([status], dtype=torch.int32, device=share.device)
-    coll.all_reduce_min(st)
-    worst = int(st.item())
-    if worst != 0:
-        raise _lib.KhgError(worst, "encode_tiled (rank %d saw status %d)" % (rank, status))
+
+    def third():
+        # The device-side status (a symbol out of range, a stream of 2^31 bits) may show on one rank only, like a
+        # host-side failure: it joins the agreement, so that all ranks raise together instead of one raising and
+        # the others waiting in the byte reduce for ever.
+        backend.bits_set(bits)
+        share, total, status = backend.pack(backend.comp_bound(rows, cols))
+        if status != 0:
+            raise _lib.KhgError(status, "tile_pack")
+        return share, total, backend.chunk_off_get() if merge == "gather" else None
+
+    share, total, off = _agreed(coll, dev, rank, "encode_tiled: pack", third)
     words = share[: (total + 3) & ~3].view(torch.int32)
     if merge == "gather":
-        words = gather_shares(words, own, bits, backend.chunk_off_get(), rank, world, coll, dst)
+        words = gather_shares(words, own, bits, off, rank, world, coll, dst)
     else:
         coll.reduce_sum(words, dst)  # the shares have no set bit in common: their sum is their OR
     if rank != dst:
@@ -335,32 +364,42 @@ def decode_tiled(backend, comp, length, rows, cols, rank, world, coll=None, spli
     if not split:
         return backend.decode(comp, length, rows, cols, rank, world)
     coll = coll or DistCollectives()
-    backend.dec_map(comp, length, rows, cols, rank, world)
-    words = backend.blk_get()
+    dev = comp.device
+
+    def first():
+        backend.dec_map(comp, length, rows, cols, rank, world)
+        return backend.blk_get()
+
+    words = _agreed(coll, dev, rank, "decode_tiled: map", first)
     coll.all_reduce_sum(words)  # other ranks' records are zero here: the sum is the union
-    backend.blk_set(words)
-    flat = backend.dec_write()  # identical on every rank (the chain runs on the summed records)
-    bounds = [flat[p * (world + 1):(p + 1) * (world + 1)] for p in range(3)]
-    need = [[backend.need_ranges(rows, cols, t, world, p) for p in range(3)] for t in range(world)]
-    sends, recvs, landing = [], [], []
-    for src, dst, p, first, count in symbol_pieces(bounds, need, world):
-        if src == rank:
-            sends.append((dst, backend.sym_get(p, first, count)))
-        elif dst == rank:
-            buf = backend.sym_buffer(count)
-            recvs.append((src, buf))
-            landing.append((p, first, buf))
+
+    def second():
+        backend.blk_set(words)
+        flat = backend.dec_write()  # identical on every rank (the chain runs on the summed records)
+        bounds = [flat[p * (world + 1):(p + 1) * (world + 1)] for p in range(3)]
+        need = [[backend.need_ranges(rows, cols, t, world, p) for p in range(3)] for t in range(world)]
+        sends, recvs, landing = [], [], []
+        for src, dst, p, first_sym, count in symbol_pieces(bounds, need, world):
+            if src == rank:
+                sends.append((dst, backend.sym_get(p, first_sym, count)))
+            elif dst == rank:
+                buf = backend.sym_buffer(count)
+                recvs.append((src, buf))
+                landing.append((p, first_sym, buf))
+        return sends, recvs, landing
+
+    sends, recvs, landing = _agreed(coll, dev, rank, "decode_tiled: write", second)
     coll.exchange(sends, recvs)
-    for p, first, buf in landing:
-        backend.sym_set(p, first, buf)
-    out, status = backend.dec_inverse()
-    # a damaged stream may show on the rank that decoded that part only: agree before anyone raises
-    st = torch.tensor([status], dtype=torch.int32, device=out.device)
-    coll.all_reduce_min(st)
-    worst = int(st.item())
-    if worst != 0:
-        raise _lib.KhgError(worst, "decode_tiled (rank %d saw status %d)" % (rank, status))
-    return out
+
+    def third():
+        for p, first_sym, buf in landing:
+            backend.sym_set(p, first_sym, buf)
+        out, status = backend.dec_inverse()
+        if status != 0:  # a damaged stream may show on the rank that decoded that part only
+            raise _lib.KhgError(status, "tile_decode_inverse")
+        return out
+
+    return _agreed(coll, dev, rank, "decode_tiled: inverse", third)
 
 
 # ---- the library's own host for the tiled mode

@@ -135,8 +135,10 @@ int khg_ordered_mean_dev(const double *d_values, size_t n, double *d_mean, void 
  * synchronisation points; a decoder must first find where codewords begin).  After khg_ctx_set_format(ctx, 2) the
  * whole-image encoders of the context (khg_encode*, not the khg_tile_* steps) append, behind the unchanged bytes of
  * format 1 -- which ReadAll (Reader.h:56-74) reads as before, never looking further -- where the first codeword of
- * every 256 bits of each stream starts and which symbol it is, plus both dimensions and 64-bit stream lengths (layout:
- * csrc/khg_index.h).  The output buffer then needs khg_comp_bound + khg_index_bound bytes (KHG_ERR_CAP otherwise).
+ * every 256 bits of each stream starts and which symbol it is, plus both dimensions and the stream lengths (layout:
+ * csrc/khg_index.h; the length fields are 64 bits wide, but encoder and decoder keep the reference's limit of 2^31
+ * bits per stream, Type.h:5, in both formats: a longer stream is KHG_ERR_RANGE, and an index whose high words are
+ * not zero is refused).  The output buffer then needs khg_comp_bound + khg_index_bound bytes (KHG_ERR_CAP otherwise).
  * khg_decode_indexed_dev is khg_decode_dev for such files: it starts its decoders from the index instead of searching
  * for the codeword boundaries first (about a third of the decoder's work); a file without a sound index is refused
  * (KHG_ERR_FORMAT through khg_last_status).  An index that lies about a sound stream yields wrong pixels, never an
@@ -183,7 +185,13 @@ int khg_downsample_dev(const uint8_t *d_src, int src_rows, int src_cols, uint8_t
  * the calling thread's current device, enqueues on `stream` and does not synchronise: the result is written to
  * DEVICE memory at d_ssim[0] (bit-identical to khg_ssim_dev's) and is valid once the stream has run.  No hipMalloc,
  * hipFree or other allocating call is made.  All calls on one GPU share the one array: calls that overlap in time
- * on a GPU (different streams) race; nothing in it needs to start at zero. */
+ * on a GPU (different streams) race; nothing in it needs to start at zero.
+ * The array's address on a device is looked up (hipGetSymbolAddress, which may load the code object) the first time
+ * the device is used: that lookup must not happen while a stream is capturing.  Call khg_ssim_static_prepare() --
+ * set-up, no compute: it does the lookup for the calling thread's current device -- or make the first
+ * khg_ssim_static_dev call on the device, before capture begins.  `stream` must belong to the current device
+ * (KHG_ERR_ARG otherwise). */
+int khg_ssim_static_prepare(void);
 int khg_ssim_static_dev(const uint8_t *d_a, const uint8_t *d_b, int width, int height, double *d_ssim, void *stream);
 
 /* ---- parity taps (device pointers, synchronous).  Any output pointer may be NULL.

@@ -12,8 +12,16 @@ def main():
     n = int(sys.argv[1])
     from khugle_amd.launch import ranks_or_spawn
     rank, local_rank, world = ranks_or_spawn(n, need_devices=False)
-    if len(sys.argv) > 2 and sys.argv[2] == "fail" and rank == 1:
+    if len(sys.argv) > 2 and sys.argv[2] in ("fail", "stubborn") and rank == 1:
+        if sys.argv[2] == "stubborn":
+            import time
+            time.sleep(1.0)  # rank 0 has its handler in place by now
         sys.exit(7)
+    if len(sys.argv) > 2 and sys.argv[2] == "stubborn":  # a rank that a collective or a GPU wait keeps from ending
+        import signal
+        import time
+        signal.signal(signal.SIGTERM, signal.SIG_IGN)
+        time.sleep(600)
     import torch
     import torch.distributed as dist
     if world > 1:

@@ -29,6 +29,15 @@ def test_one_failing_rank_fails_the_job():
     assert p.returncode != 0
 
 
+def test_a_rank_that_ignores_sigterm_is_killed():
+    import time
+    env = dict(_clean_env(), KHG_LAUNCH_KILL_AFTER="1")
+    t0 = time.monotonic()
+    p = subprocess.run([sys.executable, PROBE, "2", "stubborn"], env=env, capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0
+    assert time.monotonic() - t0 < 60
+
+
 def test_world_size_of_an_external_launcher_must_match():
     env = dict(_clean_env(), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
     p = subprocess.run([sys.executable, PROBE, "2"], env=env, capture_output=True, text=True, timeout=300)

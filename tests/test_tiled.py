@@ -228,6 +228,47 @@ def test_a_failing_tile_fails_every_rank_instead_of_hanging(tmp_path):
         assert open(os.path.join(str(tmp_path), "rank%d.txt" % r)).read() == "raised -4"
 
 
+@pytest.mark.parametrize("step", ["forward", "lens", "chunk_off_get", "dec_map", "dec_write", "blk_set", "dec_inverse"])
+def test_a_host_side_failure_on_one_rank_raises_on_all(step):
+    """A step whose entry point fails on one rank only (here: a busy context, -8, on rank 1) raises on every rank at
+    the next agreement instead of leaving the others in a collective."""
+    from khugle_amd import tiled
+    from khugle_amd.lib import KhgError
+    from khugle_amd.synth import synth_frame
+    import oracle_py as O
+    import simlib as S
+    from tiledlib import run_ranks
+    rows, cols, world, lvl = 128, 96, 2, 1
+    rgb = synth_frame(rows, cols, 11, 0)
+    want = O.encode(rgb, lvl)
+    comp_t = torch.from_numpy(np.frombuffer(want + b"\0" * 8, np.uint8).copy())
+
+    def backend(rank):
+        be = S.SimTileBackend(rows, cols)
+        if rank == 1:
+            inner = getattr(be, step)
+
+            def failing(*a, **k):
+                raise KhgError(-8, step)
+            setattr(be, step, failing)
+            assert inner is not None
+        return be
+
+    def rank_fn(rank, coll):
+        be = backend(rank)
+        try:
+            if step in ("forward", "lens", "chunk_off_get"):
+                tiled.encode_tiled(be, _strip(rgb, rows, rank, world), rows, cols, lvl, rank, world, coll=coll,
+                                   merge="gather" if step == "chunk_off_get" else "reduce")
+            else:
+                tiled.decode_tiled(be, comp_t, len(want), rows, cols, rank, world, coll=coll)
+            return 0
+        except KhgError as e:
+            return e.code
+
+    assert run_ranks(world, rank_fn) == [-8, -8]
+
+
 def test_tile_geometry():
     from khugle_amd import tiled
     assert tiled.tile_rows(256, 1, 4) == (64, 128)

@@ -38,3 +38,47 @@ def test_static_scratch_entry_point_matches_and_allocates_nothing(codec):
     rc = L.khg_ssim_static_dev(C.c_void_p(big.data_ptr()), C.c_void_p(big.data_ptr()), 7680, 4328,
                                C.c_void_p(out.data_ptr()), C.c_void_p(0))
     assert rc == lib.ERR_DIMS
+
+
+_COLD = r"""
+import ctypes as C, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[2])
+import numpy as np, torch
+import oracle_py as O
+from khugle_amd import lib
+from khugle_amd.synth import synth_frame
+a, b = synth_frame(264, 520, 2025, 1), synth_frame(264, 520, 2025, 8)
+da, db = torch.from_numpy(a[0]).cuda(), torch.from_numpy(b[0]).cuda()
+out = torch.zeros(1, dtype=torch.float64, device="cuda")
+s = torch.cuda.Stream()
+torch.cuda.synchronize()
+L = lib.load()  # nothing of the library has run in this process
+if sys.argv[3] == "prepare":
+    assert L.khg_ssim_static_prepare() == 0
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):  # the call itself under stream capture
+        rc = L.khg_ssim_static_dev(C.c_void_p(da.data_ptr()), C.c_void_p(db.data_ptr()), 520, 264,
+                                   C.c_void_p(out.data_ptr()), C.c_void_p(s.cuda_stream))
+    assert rc == 0
+    g.replay()
+else:
+    rc = L.khg_ssim_static_dev(C.c_void_p(da.data_ptr()), C.c_void_p(db.data_ptr()), 520, 264,
+                               C.c_void_p(out.data_ptr()), C.c_void_p(s.cuda_stream))
+    assert rc == 0
+torch.cuda.synchronize()
+assert float(out[0].item()) == O.ssim(a[0], b[0]), (float(out[0].item()), O.ssim(a[0], b[0]))
+print("cold ok")
+"""
+
+
+@pytest.mark.parametrize("mode", ["first_call", "prepare"])
+def test_cold_first_call_in_a_fresh_process(mode):
+    """khg_ssim_static_dev as the very first library call of a process (the code object and the array's address are
+    not known yet), and -- after khg_ssim_static_prepare -- recorded into a HIP graph and replayed."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    p = subprocess.run([sys.executable, "-c", _COLD, os.path.join(ROOT, "image-compression_amd", "python"),
+                        os.path.join(ROOT, "oracle"), mode], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "cold ok" in p.stdout, p.stdout + p.stderr
