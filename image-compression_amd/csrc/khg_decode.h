@@ -557,9 +557,12 @@ KHG_DEV uint64_t khg_mask_range(uint32_t rel, uint32_t r)
 }
 
 // LDS of the map kernel.  MO = start offsets it has room for: with 32 (codes up to 32 bits, i.e. nearly every
-// stream) a workgroup needs 52.6 KB and three fit on a CU; streams with longer codes are handled by the
-// KHG_MAXOFF instantiation (two per CU).  A launch of either does nothing for planes that belong to the other.
-enum { KHG_MAP_SMALL = 32 };
+// stream) a workgroup needs 39.7 KB and four fit on a CU; streams with longer codes are handled by the
+// KHG_MAXOFF instantiation (three per CU).  A launch of either does nothing for planes that belong to the other.
+#ifndef KHG_MAP_THREADS_CFG
+#define KHG_MAP_THREADS_CFG (2 * KHG_DEC_BLOCK)
+#endif
+enum { KHG_MAP_SMALL = 32, KHG_MAP_THREADS = KHG_MAP_THREADS_CFG };  // two threads per subsequence (khg_dec_map_body)
 template <int MO>
 struct KhgDecSmem {
     uint8_t len8[KHG_LUT_SIZE];                    // see khg_len_at
@@ -567,6 +570,8 @@ struct KhgDecSmem {
     uint32_t mask[(KHG_SUB_WORDS + 1) * KHG_DEC_BLOCK];  // word-major: thread t's word w at [w * 256 + t]; a subsequence
                                                          // that starts inside a staged word reaches into one more
     uint16_t map[MO * KHG_DEC_BLOCK];              // offset-major: thread t's entry for offset o at [o * 256 + t]
+    uint32_t main_arr[KHG_DEC_BLOCK];              // where subsequence t's recording run lands
+    uint32_t next_oo[KHG_DEC_BLOCK];               // ... and the offset it started from (lower ones may still run on)
 };
 
 // Stage the LUT and the workgroup's span of the stream (byte-swapped words) in LDS.
@@ -602,13 +607,13 @@ KHG_DEV KhgBitsL khg_dec_stage_lens(const KhgDecArgs& a, int p, uint32_t blk_beg
     const uint32_t* glut = a.lut + (size_t)p * KHG_LUT_SIZE;
     const uint64_t gbit = 8ull * a.hdr->stream_byte[p] + blk_begin;
     const uint32_t w0 = (uint32_t)(gbit >> 5);
-    KHG_FOR_THREADS(256)
+    KHG_FOR_THREADS(KHG_MAP_THREADS)
     {
-        for (int i = tid; i < KHG_LUT_SIZE; i += 256) {
+        for (int i = tid; i < KHG_LUT_SIZE; i += KHG_MAP_THREADS) {
             const uint32_t e = glut[i];
             sh.len8[i] = (e & 0x80000000u) ? (uint8_t)((e >> 16) & 0xFF) : (uint8_t)0;
         }
-        for (uint32_t i = (uint32_t)tid; i < KHG_STAGE_WORDS; i += 256) {
+        for (uint32_t i = (uint32_t)tid; i < KHG_STAGE_WORDS; i += KHG_MAP_THREADS) {
             uint32_t w = w0 + i;
             sh.stage[khg_stage_slot(i)] = w < nwords ? khg_bswap32(words[w]) : 0;
         }
@@ -652,53 +657,67 @@ KHG_DEV void khg_dec_map_body(const KhgDecArgs& a, uint32_t blk, KhgDecSmem<MO>&
     // first staged word of the subsequence: lr = (position in the subsequence) + s0, the same s0 < 32 for every
     // thread (subsequences are 256 bits, a whole number of words, apart).
     const uint32_t s0 = (blk_begin - bits.bias) & 31u;
-    KHG_FOR_THREADS(256)
+    // Two threads per subsequence: thread t and thread 256 + t share subsequence t's columns of `map` and `mask`
+    // and split its start offsets by parity.  Where runs never rejoin (stretches of near-equal code lengths: the
+    // LL band) a subsequence has one whole-length run per offset, and the workgroups of those stretches last
+    // longest -- the launch lasts as long as they do; halving their threads' chains of dependent steps is what
+    // shortens it.  The recording run in between is one thread's work (the partner waits at the barrier).
+#define KHG_MAP_THREAD_SETUP                                                                                       \
+        const int t = tid & (KHG_DEC_BLOCK - 1);                                                                   \
+        const uint32_t half = (uint32_t)tid >> 8;                                                                  \
+        const uint32_t sub_begin = blk_begin + (uint32_t)t * KHG_SUB_BITS;                                         \
+        const uint32_t end = sub_begin + KHG_SUB_BITS < nbits ? sub_begin + KHG_SUB_BITS : nbits;                  \
+        const uint32_t lr_of = s0 - sub_begin;            /* lr = pos + lr_of */                                   \
+        const uint32_t end_lr = sub_begin < end ? end + lr_of : 0;  /* first lr behind the subsequence (or the stream) */ \
+        const uint32_t nb_lr = nbits + lr_of;             /* first lr behind the stream (sub_begin < nbits: no wrap) */ \
+        const uint32_t wbase = (uint32_t)t * KHG_SUB_WORDS;  /* first staged word of the subsequence */           \
+        uint16_t* map = &sh.map[t];                                                                                \
+        uint32_t* mask = &sh.mask[t];                                                                              \
+        (void)half; (void)lr_of; (void)end_lr; (void)nb_lr; (void)wbase; (void)map; (void)mask;
+
+    // 1. first codeword from every start offset: where does it land?  The offsets lie in the first three words.
+    KHG_FOR_THREADS(KHG_MAP_THREADS)
     {
-        const uint32_t sub_begin = blk_begin + (uint32_t)tid * KHG_SUB_BITS;
-        const uint32_t end = sub_begin + KHG_SUB_BITS < nbits ? sub_begin + KHG_SUB_BITS : nbits;
-        const uint32_t lr_of = s0 - sub_begin;            // lr = pos + lr_of
-        const uint32_t end_lr = sub_begin < end ? end + lr_of : 0;  // first lr behind the subsequence (or the stream)
-        const uint32_t nb_lr = nbits + lr_of;             // first lr behind the stream (sub_begin < nbits: no wrap)
-        const uint32_t wbase = (uint32_t)tid * KHG_SUB_WORDS;  // first staged word of the subsequence
-        uint16_t* map = &sh.map[tid];
-        uint32_t* mask = &sh.mask[tid];
-        // 1. first codeword from every start offset: where does it land?  The offsets lie in the first three words.
-        {
-            const uint32_t w0 = bits.stage[khg_stage_slot(wbase)], w1 = bits.stage[khg_stage_slot(wbase + 1)],
-                           w2 = bits.stage[khg_stage_slot(wbase + 2)], w3 = bits.stage[khg_stage_slot(wbase + 3)];
-            for (uint32_t o = 0; o < M; ++o) {
-                const uint32_t lr = s0 + o, j = lr >> 5, sh_ = lr & 31u;
-                uint16_t e = khg_map_entry(KHG_OFF_NONE, 0);
-                if (lr < end_lr) {
-                    const uint32_t hi = j == 0 ? w0 : j == 1 ? w1 : w2, lo = j == 0 ? w1 : j == 1 ? w2 : w3;
-                    const uint32_t win = (uint32_t)(((((uint64_t)hi << 32) | lo) << sh_) >> 32);
-                    uint32_t len = sh.len8[win >> (32 - KHG_LUT_BITS)];
-                    if (len == 0) {  // longer than the first-level table: the general decoder
-                        int sy;
-                        len = khg_decode_one(bits, glut, lut2, left, right, tsym, sub_begin + o, &sy);
-                    } else if (lr + len > nb_lr) {
-                        len = 0;  // the stream ends inside this codeword
-                    }
-                    if (len) e = khg_map_entry(KHG_OFF_TEMP, o + len);  // landing offset < 2 * 56
+        KHG_MAP_THREAD_SETUP
+        const uint32_t w0 = bits.stage[khg_stage_slot(wbase)], w1 = bits.stage[khg_stage_slot(wbase + 1)],
+                       w2 = bits.stage[khg_stage_slot(wbase + 2)], w3 = bits.stage[khg_stage_slot(wbase + 3)];
+        for (uint32_t o = half; o < M; o += 2) {
+            const uint32_t lr = s0 + o, j = lr >> 5, sh_ = lr & 31u;
+            uint16_t e = khg_map_entry(KHG_OFF_NONE, 0);
+            if (lr < end_lr) {
+                const uint32_t hi = j == 0 ? w0 : j == 1 ? w1 : w2, lo = j == 0 ? w1 : j == 1 ? w2 : w3;
+                const uint32_t win = (uint32_t)(((((uint64_t)hi << 32) | lo) << sh_) >> 32);
+                uint32_t len = sh.len8[win >> (32 - KHG_LUT_BITS)];
+                if (len == 0) {  // longer than the first-level table: the general decoder
+                    int sy;
+                    len = khg_decode_one(bits, glut, lut2, left, right, tsym, sub_begin + o, &sy);
+                } else if (lr + len > nb_lr) {
+                    len = 0;  // the stream ends inside this codeword
                 }
-                map[o * KHG_DEC_BLOCK] = e;
+                if (len) e = khg_map_entry(KHG_OFF_TEMP, o + len);  // landing offset < 2 * 56
             }
+            map[o * KHG_DEC_BLOCK] = e;
         }
-        // 2. offsets whose first codeword leaves the first M bits run on.  The first such run (from the highest
-        //    offset) goes through the whole subsequence and records its codeword starts; every other run stops as
-        //    soon as it lands on one of them (inside a run of the 1-bit code every position is one).  Most rejoin
-        //    within a few codewords; a stretch of near-equal code lengths has one run per residue class that never
-        //    does.
-        //    The inner loops are straight-line code with one exit at the bottom (the lanes of a wave stay in one
-        //    loop); whatever is rare -- a code beyond the first-level table, the end of the stream -- leaves them
-        //    and is dealt with once per word.
-        int oo = (int)M;
-        bool have_main = false;
-        uint32_t main_arr = KHG_OFF_NONE;
-        for (uint32_t w = 0; w <= KHG_SUB_WORDS; ++w) mask[w * KHG_DEC_BLOCK] = 0;
-        const uint32_t runx = onebit < 0 ? 0xFFFFFFFFu : 0u;       // planes without a 1-bit code: no runs
-        const uint32_t runflip = onebit > 0 ? 0xFFFFFFFFu : 0u;    // the run's bits read as zeros
-        for (;;) {
+        if (half == 0)
+            for (uint32_t w = 0; w <= KHG_SUB_WORDS; ++w) mask[w * KHG_DEC_BLOCK] = 0;
+    }
+    KHG_BARRIER();
+    // 2. offsets whose first codeword leaves the first M bits run on.  The first such run (from the highest
+    //    offset) goes through the whole subsequence and records its codeword starts; every other run stops as
+    //    soon as it lands on one of them (inside a run of the 1-bit code every position is one).  Most rejoin
+    //    within a few codewords; a stretch of near-equal code lengths has one run per residue class that never
+    //    does.
+    //    The inner loops are straight-line code with one exit at the bottom (the lanes of a wave stay in one
+    //    loop); whatever is rare -- a code beyond the first-level table, the end of the stream -- leaves them
+    //    and is dealt with once per word.
+    const uint32_t runx = onebit < 0 ? 0xFFFFFFFFu : 0u;       // planes without a 1-bit code: no runs
+    const uint32_t runflip = onebit > 0 ? 0xFFFFFFFFu : 0u;    // the run's bits read as zeros
+    // 2a. the recording run; a run of the 1-bit code is stepped over at once (as far as the word goes)
+    KHG_FOR_THREADS(KHG_MAP_THREADS)
+    {
+        KHG_MAP_THREAD_SETUP
+        if (half == 0) {
+            int oo = (int)M;
             bool found = false;
             uint32_t ro = 0, lr = 0;
             while (oo > 0) {
@@ -711,11 +730,10 @@ KHG_DEV void khg_dec_map_body(const KhgDecArgs& a, uint32_t blk, KhgDecSmem<MO>&
                     break;
                 }
             }
-            if (!found) break;
-            uint32_t n = 1, join = 0xFFFFFFFFu;
-            bool dead = false;
-            if (!have_main) {
-                // the recording run; a run of the 1-bit code is stepped over at once (as far as the word goes)
+            uint32_t main_arr = KHG_OFF_NONE;
+            if (found) {
+                uint32_t n = 1;
+                bool dead = false;
                 if (lr < end_lr) {
                     uint32_t j = lr >> 5, adv = 0;
                     uint32_t wa = bits.stage[khg_stage_slot(wbase + j)];
@@ -760,24 +778,62 @@ KHG_DEV void khg_dec_map_body(const KhgDecArgs& a, uint32_t blk, KhgDecSmem<MO>&
                         mask[(at >> 5) * KHG_DEC_BLOCK] &= ~(0x80000000u >> (at & 31u));
                     }
                 }
-            } else if (lr < end_lr) {
+                if (dead || lr >= nb_lr) main_arr = KHG_OFF_NONE;
+                else main_arr = lr - (s0 + KHG_SUB_BITS);  // behind the subsequence: an overshoot < M
+                map[ro * KHG_DEC_BLOCK] = khg_map_entry(main_arr, n);
+            }
+            sh.main_arr[t] = main_arr;
+            sh.next_oo[t] = found ? ro : 0u;  // offsets below this one may still run on
+#ifdef KHG_TIMING
+            if (tid == 0) a.blk[blk].pad_[4] = (uint32_t)wall_clock64();
+#endif
+        }
+    }
+    KHG_BARRIER();
+    // 2b. the other runs, split between the subsequence's two threads by the parity of the offset (a thread reads
+    //     and finishes entries of its own parity only)
+    KHG_FOR_THREADS(KHG_MAP_THREADS)
+    {
+        KHG_MAP_THREAD_SETUP
+        const uint32_t main_arr = sh.main_arr[t];
+        int oo = (int)sh.next_oo[t];
+        for (;;) {
+            bool found = false;
+            uint32_t ro = 0, lr = 0;
+            while (oo > 0) {
+                --oo;
+                // (An entry of the partner's parity is read and ignored.  Skipping it with a `continue` in front of
+                // the load made ROCm 7.2's compiler produce wrong codeword counts on gfx950; the simulator's build
+                // was right either way.)
+                const uint16_t e0 = map[oo * KHG_DEC_BLOCK];
+                if (((uint32_t)oo & 1u) == half && khg_map_arr(e0) == KHG_OFF_TEMP && khg_map_cnt(e0) >= M) {
+                    found = true;
+                    ro = (uint32_t)oo;
+                    lr = s0 + khg_map_cnt(e0);
+                    break;
+                }
+            }
+            if (!found) break;
+            uint32_t n = 1, join = 0xFFFFFFFFu;
+            bool dead = false;
+            if (lr < end_lr) {
                 uint32_t j = lr >> 5;
                 uint32_t wa = bits.stage[khg_stage_slot(wbase + j)];
                 for (;;) {
                     const uint32_t wb = bits.stage[khg_stage_slot(wbase + j + 1)];
                     const uint32_t mw = mask[j * KHG_DEC_BLOCK];
                     const uint32_t lim = end_lr < 32u * (j + 1) ? end_lr : 32u * (j + 1);
-                    uint32_t t, len;
+                    uint32_t tt, len;
                     do {
                         const uint32_t sh_ = lr & 31u;
                         const uint32_t win = (uint32_t)(((((uint64_t)wa << 32) | wb) << sh_) >> 32);
-                        t = mw << sh_;  // top bit: a start of the recording run, identical from here on
+                        tt = mw << sh_;  // top bit: a start of the recording run, identical from here on
                         len = sh.len8[win >> (32 - KHG_LUT_BITS)];
-                        len = (int32_t)t < 0 ? 0u : len;
+                        len = (int32_t)tt < 0 ? 0u : len;
                         lr += len;
                         n += len ? 1u : 0u;
                     } while (len != 0 && lr < lim);
-                    if ((int32_t)t < 0) {
+                    if ((int32_t)tt < 0) {
                         join = lr;
                         break;
                     }
@@ -814,26 +870,27 @@ KHG_DEV void khg_dec_map_body(const KhgDecArgs& a, uint32_t blk, KhgDecSmem<MO>&
             } else {
                 arr = lr - (s0 + KHG_SUB_BITS);  // behind the subsequence: an overshoot < M
             }
-            if (!have_main) {
-                main_arr = arr;
-                have_main = true;
-#ifdef KHG_TIMING
-                if (tid == 0) a.blk[blk].pad_[4] = (uint32_t)wall_clock64();
-#endif
-            }
             map[ro * KHG_DEC_BLOCK] = khg_map_entry(arr, n);
         }
-        // 3. the other offsets reuse the entry of the offset their first codeword lands on
-        for (uint32_t o3 = M; o3-- > 0;) {
-            const uint16_t e0 = map[o3 * KHG_DEC_BLOCK];
-            if (khg_map_arr(e0) != KHG_OFF_TEMP) continue;
-            const uint16_t r = map[khg_map_cnt(e0) * KHG_DEC_BLOCK];  // landing offset > o3: already final
-            map[o3 * KHG_DEC_BLOCK] = khg_map_entry(khg_map_arr(r), khg_map_cnt(r) + 1);
+    }
+    KHG_BARRIER();
+    // 3. the other offsets reuse the entry of the offset their first codeword lands on
+    KHG_FOR_THREADS(KHG_MAP_THREADS)
+    {
+        KHG_MAP_THREAD_SETUP
+        if (half == 0) {
+            for (uint32_t o3 = M; o3-- > 0;) {
+                const uint16_t e0 = map[o3 * KHG_DEC_BLOCK];
+                if (khg_map_arr(e0) != KHG_OFF_TEMP) continue;
+                const uint16_t r = map[khg_map_cnt(e0) * KHG_DEC_BLOCK];  // landing offset > o3: already final
+                map[o3 * KHG_DEC_BLOCK] = khg_map_entry(khg_map_arr(r), khg_map_cnt(r) + 1);
+            }
         }
 #ifdef KHG_TIMING
         if (tid == 0) a.blk[blk].pad_[5] = (uint32_t)wall_clock64();
 #endif
     }
+#undef KHG_MAP_THREAD_SETUP
     KHG_BARRIER();
     // Compose the 256 subsequence maps.  For a workgroup entered at offset o the result is its own map entry
     // (landing offset, codewords) and, for every subsequence t, the offset it is entered at and the codewords
@@ -845,9 +902,9 @@ KHG_DEV void khg_dec_map_body(const KhgDecArgs& a, uint32_t blk, KhgDecSmem<MO>&
     // table.  The start masks are dead by now and lend their memory to the two small tables.
     uint32_t* gmap = sh.mask;            // [16][MO]: group g entered at o -> (landing offset << 24) | codewords
     uint32_t* gent = sh.mask + 16 * MO;  // [16][MO]: workgroup entered at o -> state at the start of group g
-    KHG_FOR_THREADS(256)
+    KHG_FOR_THREADS(KHG_MAP_THREADS)
     {
-        for (uint32_t idx = (uint32_t)tid; idx < 16 * M; idx += 256) {
+        for (uint32_t idx = (uint32_t)tid; idx < 16 * M; idx += KHG_MAP_THREADS) {
             const uint32_t g = idx / M, o = idx - g * M;
             uint32_t off = o, tot = 0;
             for (uint32_t t = 16 * g; t < 16 * g + 16; ++t) {
@@ -861,7 +918,7 @@ KHG_DEV void khg_dec_map_body(const KhgDecArgs& a, uint32_t blk, KhgDecSmem<MO>&
         }
     }
     KHG_BARRIER();
-    KHG_FOR_THREADS(256)
+    KHG_FOR_THREADS(KHG_MAP_THREADS)
     {
         if ((uint32_t)tid < M) {
             uint32_t off = (uint32_t)tid, tot = 0;
@@ -877,10 +934,10 @@ KHG_DEV void khg_dec_map_body(const KhgDecArgs& a, uint32_t blk, KhgDecSmem<MO>&
         }
     }
     KHG_BARRIER();
-    KHG_FOR_THREADS(256)
+    KHG_FOR_THREADS(KHG_MAP_THREADS)
     {
         uint32_t* gw = a.walk + (size_t)blk * KHG_MAXOFF * KHG_DEC_BLOCK;
-        for (uint32_t idx = (uint32_t)tid; idx < 16 * M; idx += 256) {
+        for (uint32_t idx = (uint32_t)tid; idx < 16 * M; idx += KHG_MAP_THREADS) {
             const uint32_t g = idx / M, o = idx - g * M;
             const uint32_t v = gent[g * MO + o];
             uint32_t off = v >> 24, tot = v & 0xFFFFFFu;

@@ -76,8 +76,8 @@ static int khg_decode_enqueue(khg_ctx* c, const uint8_t* d_comp, size_t len, int
     if (indexed) {  // the file says where codewords start (khg_index.h); KHG_ERR_FORMAT if it does not
         hipLaunchKernelGGL(khg_dec_index_kernel, dim3(grid_dec + 3), dim3(256), 0, st, d, grid_dec);
     } else {
-        hipLaunchKernelGGL((khg_dec_map_kernel<KHG_MAP_SMALL>), dim3(grid_dec), dim3(256), 0, st, d);
-        hipLaunchKernelGGL((khg_dec_map_kernel<KHG_MAXOFF>), dim3(grid_dec), dim3(256), 0, st, d);
+        hipLaunchKernelGGL((khg_dec_map_kernel<KHG_MAP_SMALL>), dim3(grid_dec), dim3(KHG_MAP_THREADS), 0, st, d);
+        hipLaunchKernelGGL((khg_dec_map_kernel<KHG_MAXOFF>), dim3(grid_dec), dim3(KHG_MAP_THREADS), 0, st, d);
         khg_launch_chain(st, d);
     }
     hipLaunchKernelGGL(khg_dec_write_kernel, dim3(grid_dec), dim3(256), 0, st, d);
@@ -358,6 +358,13 @@ extern "C" int khg_debug_fwd(uint32_t* host, size_t words)
 extern "C" int khg_debug_packer(khg_ctx* c, uint64_t* host, size_t words)
 {
     KHG_HIP(hipMemcpy(host, c->ws.chunk_off, words * 8, hipMemcpyDeviceToHost));
+    return KHG_OK;
+}
+// Developer build only: the walk table of one workgroup of the last decode (KHG_DEC_BLOCK * KHG_MAXOFF words).
+extern "C" int khg_debug_walk(khg_ctx* c, uint32_t blk, uint32_t* host)
+{
+    KHG_HIP(hipMemcpy(host, c->dws.walk + (size_t)blk * KHG_MAXOFF * KHG_DEC_BLOCK, (size_t)KHG_MAXOFF * KHG_DEC_BLOCK * 4,
+                      hipMemcpyDeviceToHost));
     return KHG_OK;
 }
 // Developer build only: the per-workgroup records of the last decode (timing stamps in pad_).

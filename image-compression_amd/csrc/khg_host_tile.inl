@@ -210,8 +210,8 @@ extern "C" int khg_tile_decode_map_dev(khg_ctx* c, const uint8_t* d_comp, size_t
     hipLaunchKernelGGL(khg_dec_tree_kernel, dim3(3), dim3(256), 0, st, d);
     const unsigned grid = khg_tdec_grid(c);
     if (grid) {
-        hipLaunchKernelGGL((khg_dec_map_kernel<KHG_MAP_SMALL>), dim3(grid), dim3(256), 0, st, d);
-        hipLaunchKernelGGL((khg_dec_map_kernel<KHG_MAXOFF>), dim3(grid), dim3(256), 0, st, d);
+        hipLaunchKernelGGL((khg_dec_map_kernel<KHG_MAP_SMALL>), dim3(grid), dim3(KHG_MAP_THREADS), 0, st, d);
+        hipLaunchKernelGGL((khg_dec_map_kernel<KHG_MAXOFF>), dim3(grid), dim3(KHG_MAP_THREADS), 0, st, d);
     }
     KHG_HIP(hipGetLastError());
     c->tdec_step = 1;

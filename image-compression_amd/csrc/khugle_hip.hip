@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void khg_dec_tree_kernel(KhgDecArgs a)
 // MO = KHG_MAP_SMALL: planes whose longest code has at most 32 bits (three workgroups per CU);
 // MO = KHG_MAXOFF: the others.  Both are launched; a workgroup of the wrong one returns at once.
 template <int MO>
-__global__ __launch_bounds__(256) void khg_dec_map_kernel(KhgDecArgs a)
+__global__ __launch_bounds__(KHG_MAP_THREADS) void khg_dec_map_kernel(KhgDecArgs a)
 {
     __shared__ KhgDecSmem<MO> sh;
     const uint32_t blk = khg_dec_dispatch_order(a, blockIdx.x);
