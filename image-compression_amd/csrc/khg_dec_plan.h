@@ -145,3 +145,14 @@ static inline KhgInvArgs khg_inv_args(const KhgWorkspace& ws, const KhgDecWorksp
     }
     return a;
 }
+
+// The fused level-1 launch (khg_inv_fused_wg_body): the grid of the luma plane; a.pl[1] and a.pl[2] describe the
+// chroma planes the same workgroups reconstruct.  r / g / b are set by the caller.
+static inline KhgInvArgs khg_inv_args_fused(const KhgWorkspace& ws, const KhgDecWorkspace& dws, int rows, int cols,
+                                            KhgTile tile = KhgTile{0, 1})
+{
+    KhgInvArgs a = khg_inv_args(ws, dws, rows, cols, 0, 1, 1, tile);
+    khg_inv_plane(&a.pl[1], ws, dws, rows, cols, 1, 1, tile, nullptr);
+    khg_inv_plane(&a.pl[2], ws, dws, rows, cols, 2, 1, tile, nullptr);
+    return a;
+}

@@ -57,10 +57,7 @@ struct KhgInvSmem {
     enum { NBAND = LEVEL == 1 ? 3 : 4 };
     double dv[NBAND * KHG_DV_N];  // divisor of band slot s at diagonal u: [s * KHG_DV_N + u]
 };
-union KhgInvSmemAny {
-    KhgInvSmem<1> l1;
-    KhgInvSmem<2> l2;
-};
+struct KhgInvFusedSmem;
 
 // Streaming state of one 1-D inverse lifting line after feeding pair j: d[j], s1[j], d1[j-1], s0[j-1].
 struct KhgILift {
@@ -340,10 +337,245 @@ KHG_DEV void khg_inv_wg_body(const KhgInvArgs& a, const KhgInvPlane& pl, int wgl
 #undef KHG_INV_KO
 }
 
+// ---- level 1 of all three components and the colour conversion in one launch.
+//
+// The launch above that turns the luma plane into RGB reads the finished Cb and Cr planes, which a launch before it
+// wrote: 8 bytes per pixel go to memory and come back.  Here the workgroup that reconstructs a block of luma rows
+// reconstructs the chroma samples under it itself: its four waves, which hold four adjacent luma strips (240
+// pairs = 240 chroma columns), are also the four chroma strips of that block (two of Cb, two of Cr, 60 pairs = 120
+// columns each).  A chroma trip finishes two chroma rows, which serve four luma rows: every other luma trip is
+// preceded by one chroma trip, whose rows go through LDS (two buffers, one barrier per chroma trip) to the lanes
+// that hold the luma pairs above them.  Same arithmetic, operation for operation, as the separate launches.
+
+#define KHG_NS KHG_NSLOT(256)
+struct KhgInvStrip {  // a thread's share of one strip's streaming state (level 1)
+    KhgILift colL[KHG_NS], colH[KHG_NS];
+    KhgInvRaw raw[KHG_NS];  // the next trip's inputs
+    int pairs[KHG_NS], colsL[KHG_NS], colsH[KHG_NS], uL[KHG_NS], uH[KHG_NS];
+    bool outl[KHG_NS];
+    const int16_t* sym[KHG_NS];
+    const double* ll[KHG_NS];
+    double LO[2][KHG_NS], HI[2][KHG_NS], S1[2][KHG_NS], D1[2][KHG_NS], S0[2][KHG_NS], X[2][KHG_NS], XO[2][KHG_NS];
+};
+
+struct KhgInvGeo {  // the plane and the workgroup's place in it: the same for every thread
+    int ph, pw, hh, hw, np, sym_pitch, ll_pitch, klo, P0;
+    const double* dv;  // 3 bands x KHG_DV_N divisors
+};
+
+// A thread (lane `lane` of the wave that holds strip s) takes its place; inside KHG_FOR_THREADS.
+KHG_DEV void khg_istrip_init(KhgInvStrip& st, int slot, const KhgInvGeo& g, int s, int lane, int ustrips,
+                             const int16_t* sym, const double* ll)
+{
+    const int v0 = KHG_STRIP_PAIRS * s, v1 = v0 + KHG_STRIP_PAIRS < g.np ? v0 + KHG_STRIP_PAIRS : g.np;
+    const int p = v0 - 2 + lane;
+    st.outl[slot] = p >= v0 && p < v1;
+    int pr = p < v0 ? v0 : (p > v0 + KHG_STRIP_PAIRS - 1 ? v0 + KHG_STRIP_PAIRS - 1 : p);
+    if (pr > g.np - 1) pr = g.np - 1;
+    st.pairs[slot] = pr;
+    st.colsL[slot] = khg_reflect(2 * p, g.pw) >> 1;
+    st.colsH[slot] = khg_reflect(2 * p + 1, g.pw) >> 1;
+    const int umax = ustrips * KHG_STRIP_PAIRS + 3;  // lanes beyond the plane: any entry of the table
+    int u = st.colsL[slot] - g.P0;
+    st.uL[slot] = u < 0 ? 0 : (u > umax ? umax : u);
+    u = st.colsH[slot] - g.P0;
+    st.uH[slot] = u < 0 ? 0 : (u > umax ? umax : u);
+    const KhgILift z = {0, 0, 0, 0};
+    st.colL[slot] = z;
+    st.colH[slot] = z;
+    st.sym[slot] = sym;
+    st.ll[slot] = ll;
+}
+
+// Divisors of the three level-1 bands along the diagonals the workgroup touches (Decompress.h:105, 120-121): pair
+// P0 + i at packed row klo + r sits on diagonal u = i + r.  Inside KHG_FOR_THREADS.
+KHG_DEV void khg_idv_fill(double* dv, const KhgInvGeo& g, const KhgQuant& qc, int lvl, int nu, int tid)
+{
+    for (int e = tid; e < 3 * nu; e += 256) {
+        const int s2 = e / nu, u = e - s2 * nu, band = 4 + s2;
+        const int by = band >= 5 ? g.hh : 0, bx = band != 5 ? g.hw : 0;
+        dv[s2 * KHG_DV_N + u] = khg_divisor(qc, band, bx + g.P0 + u, by + g.klo, lvl);
+    }
+}
+
+// Loads of trip j; inside KHG_FOR_THREADS.
+KHG_DEV void khg_istrip_fetch(KhgInvStrip& st, int slot, const KhgInvGeo& g, int j)
+{
+    const int ke = khg_reflect(2 * j, g.ph) >> 1, ko = g.hh + (khg_reflect(2 * j + 1, g.ph) >> 1);
+    const uint32_t oe = (uint32_t)ke * (uint32_t)g.sym_pitch, oo = (uint32_t)ko * (uint32_t)g.sym_pitch;
+    const uint32_t cl = (uint32_t)st.colsL[slot], ch = (uint32_t)(g.hw + st.colsH[slot]);
+    const int16_t* sym = st.sym[slot];
+    KhgInvRaw r;
+    r.ll = st.ll[slot][(uint32_t)ke * (uint32_t)g.ll_pitch + cl];
+    r.q[0] = 0;
+    r.q[1] = sym[oe + ch];
+    r.q[2] = sym[oo + cl];
+    r.q[3] = sym[oo + ch];
+    r.cb = r.cr = 0.0;
+    st.raw[slot] = r;
+}
+
+// Trip j of a strip: afterwards S0[rr] / XO[rr] hold the lane's even / odd sample of the natural rows 2 (j - 2) + rr.
+// A workgroup collective (not inside KHG_FOR_THREADS).
+KHG_DEV void khg_istrip_trip(KhgInvStrip& st, const KhgInvGeo& g, int j)
+{
+    KHG_FOR_THREADS(256)
+    {
+        const KhgInvRaw raw = st.raw[KHG_SLOT];
+        const int re = (khg_reflect(2 * j, g.ph) >> 1) - g.klo, ro = (khg_reflect(2 * j + 1, g.ph) >> 1) - g.klo;
+        const double c0 = raw.ll;
+        const double c1 = (double)raw.q[1] * g.dv[0 * KHG_DV_N + st.uH[KHG_SLOT] + re];  // band 4: (ke, hw + column)
+        const double c2 = (double)raw.q[2] * g.dv[1 * KHG_DV_N + st.uL[KHG_SLOT] + ro];  // band 5: (hh + ko, column)
+        const double c3 = (double)raw.q[3] * g.dv[2 * KHG_DV_N + st.uH[KHG_SLOT] + ro];  // band 6: (hh + ko, hw + column)
+        khg_istrip_fetch(st, KHG_SLOT, g, j + 1);  // in flight during this trip's arithmetic
+        khg_inv_step(st.colL[KHG_SLOT], c0, c2, st.LO[0][KHG_SLOT], st.LO[1][KHG_SLOT]);
+        khg_inv_step(st.colH[KHG_SLOT], c1, c3, st.HI[0][KHG_SLOT], st.HI[1][KHG_SLOT]);
+        KHG_UNROLL
+        for (int rr = 0; rr < 2; ++rr) {
+            st.LO[rr][KHG_SLOT] = khg_inv_unscale_low(st.LO[rr][KHG_SLOT]);
+            st.HI[rr][KHG_SLOT] = khg_inv_unscale_high(st.HI[rr][KHG_SLOT]);
+        }
+    }
+    for (int rr = 0; rr < 2; ++rr) KHG_LANE_PREV(st.X[rr], st.HI[rr])
+    KHG_FOR_THREADS(256)
+    {
+        KHG_UNROLL
+        for (int rr = 0; rr < 2; ++rr)
+            st.S1[rr][KHG_SLOT] = st.LO[rr][KHG_SLOT] + KHG_C1 * (st.X[rr][KHG_SLOT] + st.HI[rr][KHG_SLOT]);
+    }
+    for (int rr = 0; rr < 2; ++rr) KHG_LANE_NEXT(st.X[rr], st.S1[rr])
+    KHG_FOR_THREADS(256)
+    {
+        KHG_UNROLL
+        for (int rr = 0; rr < 2; ++rr)
+            st.D1[rr][KHG_SLOT] = st.HI[rr][KHG_SLOT] + KHG_C2 * (st.S1[rr][KHG_SLOT] + st.X[rr][KHG_SLOT]);
+    }
+    for (int rr = 0; rr < 2; ++rr) KHG_LANE_PREV(st.X[rr], st.D1[rr])
+    KHG_FOR_THREADS(256)
+    {
+        KHG_UNROLL
+        for (int rr = 0; rr < 2; ++rr)
+            st.S0[rr][KHG_SLOT] = st.S1[rr][KHG_SLOT] + KHG_C3 * (st.X[rr][KHG_SLOT] + st.D1[rr][KHG_SLOT]);
+    }
+    for (int rr = 0; rr < 2; ++rr) KHG_LANE_NEXT(st.X[rr], st.S0[rr])
+    KHG_FOR_THREADS(256)
+    {
+        KHG_UNROLL
+        for (int rr = 0; rr < 2; ++rr)
+            st.XO[rr][KHG_SLOT] = st.D1[rr][KHG_SLOT] + KHG_C4 * (st.S0[rr][KHG_SLOT] + st.X[rr][KHG_SLOT]);
+    }
+}
+
+enum { KHG_FUSED_COLS = KHG_WG_STRIPS * KHG_STRIP_PAIRS };  // chroma columns under a workgroup's luma strips
+struct KhgInvFusedSmem {
+    double dv[3 * KHG_DV_N];    // the luma plane's divisors
+    double dvc[3 * KHG_DV_N];   // the chroma planes' (Cb and Cr share their quantiser constants)
+    double cx[2][2][2][KHG_FUSED_COLS];  // [buffer][Cb, Cr][row of the pair][column - the workgroup's first column]
+};
+
+// One workgroup of the fused launch: the segment of luma rows [r0, r1) of four adjacent strips of a.pl[0], from
+// a.pl[0] (luma), a.pl[1] (Cb) and a.pl[2] (Cr), into the RGB image or the BMP pixel array.
+template <int OUT>
+KHG_DEV void khg_inv_fused_wg_body(const KhgInvArgs& a, int wgl, KhgInvFusedSmem& sh)
+{
+    if (!a.hdr->ok) return;
+    const int lvl = a.hdr->lvl;
+    const KhgInvPlane& pl = a.pl[0];
+    const KhgInvPlane& pc = a.pl[1];
+    const int swg = wgl % pl.nstrip_wg, seg = wgl / pl.nstrip_wg;
+    int r0, r1;
+    khg_segment_rows(pl.row_begin, pl.row_end, pl.nseg, seg, &r0, &r1);
+    const int k0 = r0 / 2, k1 = r1 / 2;            // luma row pairs = chroma rows [k0, k1)
+    const int kc0 = k0 >> 1, kc1 = (k1 + 1) >> 1;  // chroma row pairs
+    KhgInvGeo gy, gc;
+    gy.ph = pl.ph; gy.pw = pl.pw; gy.hh = pl.ph / 2; gy.hw = pl.pw / 2; gy.np = pl.pw / 2;
+    gy.sym_pitch = pl.sym_pitch; gy.ll_pitch = pl.ll_pitch;
+    gy.klo = k0 - 4 < 0 ? 0 : k0 - 4;
+    gy.P0 = KHG_STRIP_PAIRS * KHG_WG_STRIPS * swg - 2;
+    gy.dv = sh.dv;
+    const int khi = k1 + 3 > gy.hh - 1 ? gy.hh - 1 : k1 + 3;
+    gc.ph = pc.ph; gc.pw = pc.pw; gc.hh = pc.ph / 2; gc.hw = pc.pw / 2; gc.np = pc.pw / 2;
+    gc.sym_pitch = pc.sym_pitch; gc.ll_pitch = pc.ll_pitch;
+    gc.klo = kc0 - 4 < 0 ? 0 : kc0 - 4;
+    gc.P0 = KHG_STRIP_PAIRS * (KHG_WG_STRIPS / 2) * swg - 2;
+    gc.dv = sh.dvc;
+    const int khic = kc1 + 3 > gc.hh - 1 ? gc.hh - 1 : kc1 + 3;
+    const int col0 = KHG_FUSED_COLS * swg;  // the workgroup's first luma pair = its first chroma column
+
+    KhgInvStrip sy, sc;
+    int cplane[KHG_NS];  // 0: the thread's wave does a strip of Cb, 1: of Cr
+    KHG_FOR_THREADS(256)
+    {
+        const int lane = tid & 63, w = KHG_UNIFORM(tid >> 6);
+        khg_istrip_init(sy, KHG_SLOT, gy, swg * KHG_WG_STRIPS + w, lane, KHG_WG_STRIPS, pl.sym, pl.ll);
+        const KhgInvPlane& mine = a.pl[1 + (w >> 1)];
+        cplane[KHG_SLOT] = w >> 1;
+        khg_istrip_init(sc, KHG_SLOT, gc, swg * (KHG_WG_STRIPS / 2) + (w & 1), lane, KHG_WG_STRIPS / 2, mine.sym, mine.ll);
+        khg_idv_fill(sh.dv, gy, pl.q[lvl], lvl, KHG_WG_STRIPS * KHG_STRIP_PAIRS + 4 + (khi - gy.klo + 1), tid);
+        khg_idv_fill(sh.dvc, gc, pc.q[lvl], lvl, (KHG_WG_STRIPS / 2) * KHG_STRIP_PAIRS + 4 + (khic - gc.klo + 1), tid);
+    }
+    KHG_BARRIER();
+    KHG_FOR_THREADS(256)
+    {
+        khg_istrip_fetch(sy, KHG_SLOT, gy, k0 - 2);
+        khg_istrip_fetch(sc, KHG_SLOT, gc, kc0 - 2);
+    }
+    // the trips that only fill the pipelines
+    for (int jc = kc0 - 2; jc <= kc0 + 1; ++jc) khg_istrip_trip(sc, gc, jc);
+    for (int j = k0 - 2; j <= k0 + 1; ++j) khg_istrip_trip(sy, gy, j);
+    for (int kc = kc0; kc < kc1; ++kc) {
+        khg_istrip_trip(sc, gc, kc + 2);  // chroma rows 2 kc and 2 kc + 1
+        KHG_FOR_THREADS(256)
+        {
+            if (sc.outl[KHG_SLOT]) {
+                const int lc = 2 * sc.pairs[KHG_SLOT] - col0;
+                KHG_UNROLL
+                for (int rr = 0; rr < 2; ++rr) {
+                    const double v[2] = {sc.S0[rr][KHG_SLOT], sc.XO[rr][KHG_SLOT]};
+                    __builtin_memcpy(&sh.cx[kc & 1][cplane[KHG_SLOT]][rr][lc], v, 16);
+                }
+            }
+        }
+        KHG_BARRIER();
+        const int m0 = 2 * kc < k0 ? k0 : 2 * kc, m1 = 2 * kc + 2 > k1 ? k1 : 2 * kc + 2;
+        for (int m = m0; m < m1; ++m) {
+            khg_istrip_trip(sy, gy, m + 2);  // luma rows 2 m and 2 m + 1, chroma row m
+            KHG_FOR_THREADS(256)
+            {
+                if (sy.outl[KHG_SLOT]) {
+                    const int pair = sy.pairs[KHG_SLOT];
+                    const double Cb = sh.cx[kc & 1][0][m & 1][pair - col0], Cr = sh.cx[kc & 1][1][m & 1][pair - col0];
+                    KHG_UNROLL
+                    for (int rr = 0; rr < 2; ++rr) {
+                        uint32_t rgb[3];
+                        khg_rgb_pair(sy.S0[rr][KHG_SLOT], sy.XO[rr][KHG_SLOT], Cb, Cr, rgb);
+                        if (OUT == KHG_OUT_BGR) {  // B0 G0 R0 B1 G1 R1, rows bottom-up
+                            uint8_t* px = a.r + (size_t)(pl.ph - 1 - (2 * m + rr)) * a.bgr_stride + 6u * (uint32_t)pair;
+                            khg_st16(px, (rgb[2] & 255u) | ((rgb[1] & 255u) << 8));
+                            khg_st16(px + 2, (rgb[0] & 255u) | (rgb[2] & 0xFF00u));
+                            khg_st16(px + 4, (rgb[1] >> 8) | (rgb[0] & 0xFF00u));
+                        } else {
+                            const uint32_t o = (uint32_t)(2 * m + rr - a.out_row0) * (uint32_t)pl.pw + 2u * (uint32_t)pair;
+                            khg_st16(a.r + o, rgb[0]);
+                            khg_st16(a.g + o, rgb[1]);
+                            khg_st16(a.b + o, rgb[2]);
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
 // Launch kinds: level 2 of the three components into their LL buffers; level 1 of planes into f64 planes (Cb and
 // Cr, or all three for the plane outputs of DecompressImage); level 1 of the luma plane into the RGB image or into
 // a BMP pixel array.
-enum { KHG_INV_PLANES2 = 0, KHG_INV_PLANES1 = 1, KHG_INV_RGB = 2, KHG_INV_BGR = 3 };
+enum { KHG_INV_PLANES2 = 0, KHG_INV_PLANES1 = 1, KHG_INV_RGB = 2, KHG_INV_BGR = 3, KHG_INV_RGB_FUSED = 4, KHG_INV_BGR_FUSED = 5 };
+union KhgInvSmemAny {
+    KhgInvSmem<1> l1;
+    KhgInvSmem<2> l2;
+    KhgInvFusedSmem f;
+};
 
 template <int KIND>
 KHG_DEV void khg_inv_launch_body(const KhgInvArgs& a, int wg, KhgInvSmemAny& sh)
@@ -353,5 +585,7 @@ KHG_DEV void khg_inv_launch_body(const KhgInvArgs& a, int wg, KhgInvSmemAny& sh)
     if constexpr (KIND == KHG_INV_PLANES2) khg_inv_wg_body<2, KHG_OUT_PLANE>(a, a.pl[p], wg - a.pl[p].wg0, sh.l2);
     else if constexpr (KIND == KHG_INV_PLANES1) khg_inv_wg_body<1, KHG_OUT_PLANE>(a, a.pl[p], wg - a.pl[p].wg0, sh.l1);
     else if constexpr (KIND == KHG_INV_RGB) khg_inv_wg_body<1, KHG_OUT_RGB>(a, a.pl[p], wg - a.pl[p].wg0, sh.l1);
-    else khg_inv_wg_body<1, KHG_OUT_BGR>(a, a.pl[p], wg - a.pl[p].wg0, sh.l1);
+    else if constexpr (KIND == KHG_INV_BGR) khg_inv_wg_body<1, KHG_OUT_BGR>(a, a.pl[p], wg - a.pl[p].wg0, sh.l1);
+    else if constexpr (KIND == KHG_INV_RGB_FUSED) khg_inv_fused_wg_body<KHG_OUT_RGB>(a, wg, sh.f);
+    else khg_inv_fused_wg_body<KHG_OUT_BGR>(a, wg, sh.f);
 }

@@ -207,14 +207,12 @@ static void sim_inverse(SimWs& S, int rows, int cols, uint8_t* r, uint8_t* g, ui
         const KhgInvArgs a = khg_inv_args(S.ws, S.dws, rows, cols, 0, 3, 1, tile, ycbcr);
         for (int wg = 0; wg < a.nwg; ++wg) khg_inv_launch_body<KHG_INV_PLANES1>(a, wg, *ish);
     } else {
-        const KhgInvArgs ac = khg_inv_args(S.ws, S.dws, rows, cols, 1, 2, 1, tile);
-        for (int wg = 0; wg < ac.nwg; ++wg) khg_inv_launch_body<KHG_INV_PLANES1>(ac, wg, *ish);
-        KhgInvArgs ay = khg_inv_args(S.ws, S.dws, rows, cols, 0, 1, 1, tile);
+        KhgInvArgs ay = khg_inv_args_fused(S.ws, S.dws, rows, cols, tile);
         ay.r = r; ay.g = g; ay.b = b;
         ay.bgr_stride = bgr_stride;
         for (int wg = 0; wg < ay.nwg; ++wg) {
-            if (bgr_stride) khg_inv_launch_body<KHG_INV_BGR>(ay, wg, *ish);
-            else khg_inv_launch_body<KHG_INV_RGB>(ay, wg, *ish);
+            if (bgr_stride) khg_inv_launch_body<KHG_INV_BGR_FUSED>(ay, wg, *ish);
+            else khg_inv_launch_body<KHG_INV_RGB_FUSED>(ay, wg, *ish);
         }
     }
     delete ish;
