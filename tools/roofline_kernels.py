@@ -27,6 +27,7 @@ def model(px, comp):
         "khg_inv_kernel<0>": (3.75 * px, "level 2: 0.75 symbols read + 3 LL f64 written"),
         "khg_inv_kernel<1>": (5.75 * px, "Cb, Cr level 1: 0.75 symbols + 1 LL read, 4 f64 planes written"),
         "khg_inv_kernel<2>": (10.5 * px, "luma level 1 + RGB: 1.5 symbols + 2 LL + 4 chroma read, 3 RGB written"),
+        "khg_inv_kernel<4>": (8.25 * px, "level 1 of Y, Cb, Cr + RGB in one launch: 2.25 symbols + 3 LL f64 read, 3 RGB written"),
         "khg_ssim_kernel": (2.0 * px + px / 8.0, "two planes read, one f64 per block written"),
         "khg_sse_kernel": (6.0 * px, "six planes read"),
         "khg_synth_kernel": (3.0 * px, "three planes written (calibration)"),
