@@ -25,6 +25,11 @@ w = buf.reshape(-1, 8)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 nl = int(sys.argv[2]) if len(sys.argv) > 2 else 688
 w = w[:n]
+live = w[:, 0] != 0
+print("workgroups with stamps:", int(live.sum()), "of", n)
+nl = int(live[:nl].sum())
+w = w[live]
+n = w.shape[0]
 t0 = w[:, 0].min()
 st = (w[:, 0] - t0).astype(np.int64) / 100.0  # us
 en = (w[:, 1] - t0).astype(np.int64) / 100.0
@@ -52,6 +57,8 @@ pro = (w[:, 6] - w[:, 0]).astype(np.int64) / 100.0
 loop = (w[:, 7] - w[:, 6]).astype(np.int64) / 100.0
 epi = (w[:, 1] - w[:, 7]).astype(np.int64) / 100.0
 print("prologue mean %.1f max %.1f  loop (wave 0) mean %.1f max %.1f  epilogue mean %.1f max %.1f us" % (pro.mean(), pro.max(), loop.mean(), loop.max(), epi.mean(), epi.max()))
+for name, sl in (("luma", slice(0, nl)), ("chroma", slice(nl, n))):
+    print("  %-6s prologue %.1f  loop %.1f  epilogue %.1f us (means)" % (name, pro[sl].mean(), loop[sl].mean(), epi[sl].mean()))
 cyc = (w[:, 5].astype(np.int64) - w[:, 4].astype(np.int64)) & 0xFFFFFFFF
 ghz = cyc / np.maximum(du, 1e-3) / 1e3
 print("shader clock held inside the workgroups: median %.2f GHz (min %.2f, max %.2f)" % (np.median(ghz), ghz.min(), ghz.max()))
