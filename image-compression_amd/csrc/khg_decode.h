@@ -39,7 +39,7 @@ enum {
     KHG_DEC_BLOCK = 256,      // subsequences per workgroup
     KHG_BLK_BITS = KHG_SUB_BITS * KHG_DEC_BLOCK,
     KHG_STAGE_WORDS = KHG_BLK_BITS / 32 + 8,  // a workgroup's span plus the longest overshoot and the cursor's read-ahead
-    KHG_STAGE_LDS = KHG_STAGE_WORDS + KHG_STAGE_WORDS / 32 + 1,  // one pad word per 32: threads read 16 words apart
+    KHG_STAGE_LDS = KHG_STAGE_WORDS + 2 * (KHG_STAGE_WORDS / 32) + 2,  // two pad words per 32 (khg_stage_slot)
     KHG_LUT_BITS = 12,
     KHG_LUT_SIZE = 1 << KHG_LUT_BITS,
     KHG_LUT2_BITS = 8,        // second-level tables: the next 8 bits after a first-level miss
@@ -385,7 +385,16 @@ KHG_DEV uint32_t khg_dec_dispatch_order(const KhgDecArgs& a, uint32_t b)
 
 // --------------------------------------------------------------- bit reader
 
-KHG_DEV uint32_t khg_stage_slot(uint32_t w) { return w + (w >> 5); }
+// Where word w of a staged span lives: two pad slots follow every 32 words, so that threads whose subsequences lie a
+// power of two words apart start in different banks.  The pad slots hold copies of the two words after them: the
+// three slots from khg_stage_slot(w) on are words w, w + 1, w + 2 for every w, which lets a reader take 96
+// consecutive stream bits with one address.
+KHG_DEV uint32_t khg_stage_slot(uint32_t w) { return w + 2 * (w >> 5); }
+KHG_DEV void khg_stage_put(uint32_t* stage, uint32_t i, uint32_t v)
+{
+    stage[khg_stage_slot(i)] = v;
+    if (i >= 32 && (i & 31) < 2) stage[khg_stage_slot(i) - 2] = v;  // the copy in the pad slots before its chunk
+}
 
 // A workgroup's span of the stream staged in LDS as byte-swapped words at khg_stage_slot() positions.
 struct KhgBitsL {
@@ -588,7 +597,7 @@ KHG_DEV KhgBitsL khg_dec_stage(const KhgDecArgs& a, int p, uint32_t blk_begin, S
         for (int i = tid; i < KHG_LUT_SIZE; i += 256) sh.lut[i] = glut[i];
         for (uint32_t i = (uint32_t)tid; i < KHG_STAGE_WORDS; i += 256) {
             uint32_t w = w0 + i;
-            sh.stage[khg_stage_slot(i)] = w < nwords ? khg_bswap32(words[w]) : 0;
+            khg_stage_put(sh.stage, i, w < nwords ? khg_bswap32(words[w]) : 0);
         }
     }
     KhgBitsL l;
@@ -615,7 +624,7 @@ KHG_DEV KhgBitsL khg_dec_stage_lens(const KhgDecArgs& a, int p, uint32_t blk_beg
         }
         for (uint32_t i = (uint32_t)tid; i < KHG_STAGE_WORDS; i += KHG_MAP_THREADS) {
             uint32_t w = w0 + i;
-            sh.stage[khg_stage_slot(i)] = w < nwords ? khg_bswap32(words[w]) : 0;
+            khg_stage_put(sh.stage, i, w < nwords ? khg_bswap32(words[w]) : 0);
         }
     }
     KhgBitsL l;
@@ -1328,32 +1337,73 @@ KHG_DEV void khg_dec_write_body(const KhgDecArgs& a, uint32_t blk, KhgDecWriteSm
             const uint32_t sub_end = blk_begin + ((uint32_t)tid + 1) * KHG_SUB_BITS;
             const uint32_t lim = a.n[p];
             const uint32_t todo = o >= lim ? 0 : (cnt < lim - o ? cnt : lim - o);  // never store past the plane
-            int16_t* q = a.sym[p] + o;
-            KhgCursor cur;
-            khg_cur_init(cur, bits, pos);
+            int16_t* const base = a.sym[p];  // 16-byte aligned (workspace)
+            int16_t* q = base + o;
+            const uint32_t g_lo = (o + 7) >> 3, g_hi = (o + todo) >> 3;  // the groups of eight that are all this thread's
+            const uint32_t ng = g_hi > g_lo ? g_hi - g_lo : 0;
+            const uint32_t fill1 = onebit >= 0 ? (uint32_t)(uint16_t)(int16_t)onesym : 0u;
+            const uint64_t fill4 = 0x0001000100010001ull * fill1;
+            uint64_t grp[2] = {fill4, fill4};
+            uint32_t gcur = 0xFFFFFFFFu;  // the group in grp; none yet
             // Each trip steps over a run of the 1-bit code (possibly empty; already filled in) and then takes one
-            // other codeword, so the lanes of a wave stay in step through "zeros, then a value".
+            // other codeword, so the lanes of a wave stay in step through "zeros, then a value".  A trip has no
+            // branch but the one for codes beyond the first-level table: it reads the 96 stream bits at its
+            // position anew (one address, see khg_stage_slot; enough for a run of 32 and a table lookup behind
+            // it) instead of topping up a window under a condition.
+            const uint32_t lend = sub_end - bits.bias, lnb = bits.nbits - bits.bias;
+            const uint32_t runx = onebit > 0 ? 0xFFFFFFFFu : 0u;  // the run's bits read as zeros
+            const uint32_t rmax = onebit >= 0 ? 32u : 0u;
+            uint32_t lpos = pos - bits.bias;  // position in the staged span
             uint32_t i = 0;
             bool go = todo != 0;
             while (go) {  // one exit, at the bottom
-                const uint32_t room = sub_end - cur.pos;  // > 0 here
-                const uint32_t r = khg_cur_runlen(cur, onebit, todo - i < room ? todo - i : room);  // 0..32
-                if (r) {
-                    khg_cur_skip(cur, bits, r);
-                    i += r;
+                const uint32_t w = lpos >> 5, sh_ = lpos & 31, sl = khg_stage_slot(w);
+                const uint32_t x0 = bits.stage[sl], x1 = bits.stage[sl + 1], x2 = bits.stage[sl + 2];
+                const uint32_t t0 = (uint32_t)(((((uint64_t)x0 << 32) | x1) << sh_) >> 32);
+                const uint32_t t1 = (uint32_t)(((((uint64_t)x1 << 32) | x2) << sh_) >> 32);
+                uint32_t rl = todo - i < lend - lpos ? todo - i : lend - lpos;  // > 0 here
+                rl = rl < rmax ? rl : rmax;
+                const uint32_t zx = t0 ^ runx;
+                uint32_t r = zx ? (uint32_t)__builtin_clz(zx) : 32u;
+                r = r < rl ? r : rl;  // 0..32
+                const uint32_t top = (uint32_t)(((((uint64_t)t0 << 32) | t1) << r) >> 32);
+                const uint32_t e = sh.lut[top >> (32 - KHG_LUT_BITS)];
+                i += r;
+                lpos += r;
+                const bool want = r < 32 && i < todo && lpos < lend;  // a run cut at 32 may simply go on
+                uint32_t len = (e >> 16) & 0xFF;
+                int sym = (int)(int16_t)(e & 0xFFFF);
+                bool whole = true;
+                if (want && !(e & 0x80000000u)) {  // longer than the first-level table
+                    len = khg_decode_one(bits, sh.lut, lut2, left, right, tsym, lpos + bits.bias, &sym);
+                    whole = len != 0;
+                    // The symbol may come from memory: it is waited for here, on the rare path.  Left pending, it
+                    // is waited for where the paths meet, and that wait also covers the previous trip's store.
+                    KHG_OPAQUE(sym);
                 }
-                go = i < todo && cur.pos < sub_end;
-                if (go && r < 32) {  // a run cut at 32 may simply go on
-                    int s;
-                    if (khg_cur_decode(cur, bits, sh.lut, lut2, left, right, tsym, &s) == 0) {
-                        go = false;  // the stream broke off
-                    } else {
-                        q[i] = (int16_t)s;
-                        ++i;
-                        go = i < todo && cur.pos < sub_end;
-                    }
-                }
+                const bool put = want && whole && lpos + len <= lnb;  // else the stream broke off
+                // Where the symbol goes: a lane's single store opens a cache line of its own, and at a mild
+                // preset most symbols are single stores (they cost as much as everything else in this kernel).
+                // The aligned groups of four symbols that lie wholly inside this thread's stretch are therefore
+                // put together in a register -- starting from what the fill left there -- and stored as 8 bytes
+                // when the thread moves on to another group; the symbols of the ragged groups at its two ends,
+                // which it shares with its neighbours, go out one by one.
+                const uint32_t idx = o + i, g = idx >> 3;
+                const bool own = want && g - g_lo < ng;
+                if (want && !own) q[i] = (int16_t)sym;
+                const bool fresh = own && g != gcur;
+                if (fresh && gcur != 0xFFFFFFFFu) __builtin_memcpy(base + 8 * (size_t)gcur, grp, 16);
+                grp[0] = fresh ? fill4 : grp[0];
+                grp[1] = fresh ? fill4 : grp[1];
+                gcur = fresh ? g : gcur;
+                const uint64_t ins = (uint64_t)(((uint32_t)sym ^ fill1) & 0xFFFFu) << (16 * (idx & 3));
+                grp[0] ^= own && !(idx & 4) ? ins : 0ull;
+                grp[1] ^= own && (idx & 4) ? ins : 0ull;
+                i += put ? 1u : 0u;
+                lpos += put ? len : 0u;
+                go = (put || !want) && i < todo && lpos < lend;
             }
+            if (gcur != 0xFFFFFFFFu) __builtin_memcpy(base + 8 * (size_t)gcur, grp, 16);
         }
 #ifdef KHG_TIMING
         if ((tid & 63) == 0) {

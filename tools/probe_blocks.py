@@ -19,7 +19,7 @@ c = Codec(H, W)
 frame = c.synth_dev(H, W, 2025, 0)
 out = torch.zeros(64 << 20, dtype=torch.uint8, device="cuda")
 dec = torch.zeros((3, H, W), dtype=torch.uint8, device="cuda")
-c.encode_dev(frame, 1, out)
+c.encode_dev(frame, int(os.environ.get("KHG_PRESET", "1")), out)
 n = c.encode_result()
 for _ in range(2):
     c.decode_dev(out, n, H, W, dec)

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""One 8K frame, one stream: encode and decode time per preset (KHG_LIB selects an alternative build)."""
+"""One 8K frame, one stream: encode and decode time per preset (KHG_LIB selects an alternative build;
+arguments: the presets to run, default 0 1 2)."""
 import os
 import sys
 import time
@@ -17,7 +18,7 @@ c = Codec(R, C_)
 f = c.synth_dev(R, C_, 2025, 0)
 out = torch.zeros(c.comp_bound(R, C_), dtype=torch.uint8, device="cuda")
 dec = torch.zeros((3, R, C_), dtype=torch.uint8, device="cuda")
-for lvl in (0, 1, 2):
+for lvl in ([int(x) for x in sys.argv[1:]] or [0, 1, 2]):
     for rep in range(2):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(10):
