@@ -450,123 +450,8 @@ KHG_DEV uint32_t khg_decode_one(const KhgBitsL& b, const uint32_t* lut, const ui
     return len;
 }
 
-// Sequential reader over the staged span: a 64-bit window kept in registers and topped up one
-// word at a time, so a codeword costs one table lookup and a few shifts.
-struct KhgCursor {
-    uint64_t buf;   // next stream bits, first bit in bit 63; at least 33 of them valid
-    uint32_t pos;   // stream position of bit 63
-    uint32_t next;  // next stage word to append
-    int avail;      // valid bits in buf
-};
-
-KHG_DEV void khg_cur_init(KhgCursor& c, const KhgBitsL& b, uint32_t pos)
-{
-    uint32_t l = pos - b.bias, w = l >> 5, s = l & 31;
-    uint64_t two = ((uint64_t)b.stage[khg_stage_slot(w)] << 32) | b.stage[khg_stage_slot(w + 1)];
-    c.buf = two << s;
-    c.avail = 64 - (int)s;
-    c.pos = pos;
-    c.next = w + 2;
-}
-
-// Decode the codeword at the cursor and step over it.  Returns its length (0 = the stream ends inside it).
-KHG_DEV uint32_t khg_cur_decode(KhgCursor& c, const KhgBitsL& b, const uint32_t* lut, const uint32_t* lut2,
-                                const int32_t* left, const int32_t* right, const int32_t* tsym, int* sym)
-{
-    const uint32_t top = (uint32_t)(c.buf >> 32);
-    const uint32_t v = top >> (32 - KHG_LUT_BITS);
-    uint32_t e = lut[v];
-    if (!(e & 0x80000000u)) {
-        e = lut2[(size_t)v * KHG_LUT2_SIZE + ((top >> (32 - KHG_LUT_BITS - KHG_LUT2_BITS)) & (KHG_LUT2_SIZE - 1))];
-        if (!(e & 0x80000000u)) {  // longer than 20 bits: bitwise tail, then re-seat the window
-            uint32_t len = khg_decode_one(b, lut, lut2, left, right, tsym, c.pos, sym);
-            if (len) khg_cur_init(c, b, c.pos + len);
-            return len;
-        }
-    }
-    const uint32_t len = (e >> 16) & 0xFF;  // <= 20
-    *sym = (int)(int16_t)(e & 0xFFFF);
-    if (c.pos + len > b.nbits) return 0;
-    c.buf <<= len;
-    c.avail -= (int)len;
-    c.pos += len;
-    if (c.avail <= 32) {
-        c.buf |= (uint64_t)b.stage[khg_stage_slot(c.next)] << (32 - c.avail);
-        c.avail += 32;
-        c.next++;
-    }
-    return len;
-}
-
-// The map kernel only needs code lengths.  len8[v] = length of the code that the KHG_LUT_BITS-bit prefix v starts
-// with, 0 if it is longer than that (then the general decoder, with the tables in global memory, finds it).
-KHG_DEV uint32_t khg_len_at(const KhgBitsL& b, const uint8_t* len8, const uint32_t* glut, const uint32_t* lut2,
-                            const int32_t* left, const int32_t* right, const int32_t* tsym, uint32_t pos)
-{
-    uint32_t len = len8[b.peek32(pos) >> (32 - KHG_LUT_BITS)];
-    if (len == 0) {
-        int s;
-        return khg_decode_one(b, glut, lut2, left, right, tsym, pos, &s);
-    }
-    return pos + len > b.nbits ? 0 : len;
-}
-
-// khg_cur_decode without the symbol.
-KHG_DEV uint32_t khg_cur_step(KhgCursor& c, const KhgBitsL& b, const uint8_t* len8, const uint32_t* glut,
-                              const uint32_t* lut2, const int32_t* left, const int32_t* right, const int32_t* tsym)
-{
-    const uint32_t len = len8[(uint32_t)(c.buf >> (64 - KHG_LUT_BITS))];
-    if (len == 0) {  // longer than the first-level table: general decoder, then re-seat the window
-        int s;
-        const uint32_t l2 = khg_decode_one(b, glut, lut2, left, right, tsym, c.pos, &s);
-        if (l2) khg_cur_init(c, b, c.pos + l2);
-        return l2;
-    }
-    if (c.pos + len > b.nbits) return 0;
-    c.buf <<= len;
-    c.avail -= (int)len;
-    c.pos += len;
-    if (c.avail <= 32) {
-        c.buf |= (uint64_t)b.stage[khg_stage_slot(c.next)] << (32 - c.avail);
-        c.avail += 32;
-        c.next++;
-    }
-    return len;
-}
-
-// Length (at most 32 and at most lim) of the run of 1-bit codewords `onebit` at the cursor; 0 if none.
-KHG_DEV uint32_t khg_cur_runlen(const KhgCursor& c, int onebit, uint32_t lim)
-{
-    if (onebit < 0) return 0;
-    const uint64_t x = onebit ? ~c.buf : c.buf;  // the run's bits read as zeros
-    uint32_t r = x ? (uint32_t)__builtin_clzll(x) : 64u;
-    r = r > 32u ? 32u : r;  // buf holds at least 33 valid bits
-    return r > lim ? lim : r;
-}
-
-// Step over r <= 32 bits.
-KHG_DEV void khg_cur_skip(KhgCursor& c, const KhgBitsL& b, uint32_t r)
-{
-    c.buf <<= r;
-    c.avail -= (int)r;
-    c.pos += r;
-    if (c.avail <= 32) {
-        c.buf |= (uint64_t)b.stage[khg_stage_slot(c.next)] << (32 - c.avail);
-        c.avail += 32;
-        c.next++;
-    }
-}
-
-// Positions rel .. rel+r-1 (r <= 32, inside the subsequence) as bits of the two mask words they touch.
-KHG_DEV uint64_t khg_mask_range(uint32_t rel, uint32_t r)
-{
-    const uint32_t b = rel & 31;
-    const uint64_t ones = r >= 32 ? 0xFFFFFFFFull : ((1ull << r) - 1);
-    return ones << (64 - b - r);
-}
-
 // LDS of the map kernel.  MO = start offsets it has room for: with 32 (codes up to 32 bits, i.e. nearly every
-// stream) a workgroup needs 39.7 KB and four fit on a CU; streams with longer codes are handled by the
+// stream) a workgroup needs 40 488 bytes and four fit on a CU (163 840 bytes); streams with longer codes are handled by the
 // KHG_MAXOFF instantiation (three per CU).  A launch of either does nothing for planes that belong to the other.
 #ifndef KHG_MAP_THREADS_CFG
 #define KHG_MAP_THREADS_CFG (2 * KHG_DEC_BLOCK)
@@ -574,7 +459,7 @@ KHG_DEV uint64_t khg_mask_range(uint32_t rel, uint32_t r)
 enum { KHG_MAP_SMALL = 32, KHG_MAP_THREADS = KHG_MAP_THREADS_CFG };  // two threads per subsequence (khg_dec_map_body)
 template <int MO>
 struct KhgDecSmem {
-    uint8_t len8[KHG_LUT_SIZE];                    // see khg_len_at
+    uint8_t len8[KHG_LUT_SIZE];                    // see khg_dec_stage_lens
     uint32_t stage[KHG_STAGE_LDS];
     uint32_t mask[(KHG_SUB_WORDS + 1) * KHG_DEC_BLOCK];  // word-major: thread t's word w at [w * 256 + t]; a subsequence
                                                          // that starts inside a staged word reaches into one more
@@ -607,7 +492,9 @@ KHG_DEV KhgBitsL khg_dec_stage(const KhgDecArgs& a, int p, uint32_t blk_begin, S
     return l;
 }
 
-// The map kernel's staging: code lengths instead of the decode table, and the workgroup's span of the stream.
+// The map kernel's staging: code lengths instead of the decode table (len8[v] = length of the code that the
+// KHG_LUT_BITS-bit prefix v starts with, 0 if it is longer than that: then the general decoder, with the tables in
+// global memory, finds it), and the workgroup's span of the stream.
 template <class SMEM>
 KHG_DEV KhgBitsL khg_dec_stage_lens(const KhgDecArgs& a, int p, uint32_t blk_begin, SMEM& sh)
 {
