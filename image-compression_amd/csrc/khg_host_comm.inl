@@ -228,7 +228,10 @@ extern "C" int khg_comm_create_rccl(khg_comm** out, int rank, int nranks, const 
     ncclComm_t c;
     KHG_NCCL(R->CommInitRank(&c, nranks, u, rank));
     khg_comm* cm = new (std::nothrow) khg_comm{rank, nranks, c, true, nullptr, nullptr, nullptr, 0, 0};
-    if (!cm) return KHG_ERR_NOMEM;
+    if (!cm) {
+        (void)R->CommDestroy(c);
+        return KHG_ERR_NOMEM;
+    }
     *out = cm;
     return KHG_OK;
 }
@@ -348,7 +351,7 @@ __device__ uint32_t khg_gather_scan(uint32_t v, KhgGatherSmem& sh)
     sh.scan[tid] = v;
     __syncthreads();
     for (uint32_t d = 1; d < 1024; d <<= 1) {
-        const uint32_t o = tid >= d ? sh.scan[tid - d] : (MAX ? 0u : 0u);
+        const uint32_t o = tid >= d ? sh.scan[tid - d] : 0u;  // the neutral element of both
         __syncthreads();
         v = MAX ? (o > v ? o : v) : v + o;
         sh.scan[tid] = v;

@@ -290,7 +290,8 @@ int khg_tile_decode_inverse_dev(khg_ctx *ctx, uint8_t *d_r, uint8_t *d_g, uint8_
  * communicator:
  *   khg_comm_create_rccl   RCCL, one process per GPU: rank 0 calls khg_comm_unique_id (128 bytes), hands the id to
  *                          the other ranks by whatever means the application has, and every rank creates its
- *                          communicator from it (a collective call).  khg_comm_wrap_rccl takes an ncclComm_t the
+ *                          communicator from it (a collective call; `device` is made and left the calling thread's
+ *                          current device).  khg_comm_wrap_rccl takes an ncclComm_t the
  *                          application already owns.  RCCL is looked up at run time (the copy the process holds,
  *                          else librccl.so.1): KHG_ERR_HIP if there is none.
  *   khg_comm_create_local  the ranks are threads of one process with their contexts on one GPU
