@@ -464,8 +464,9 @@ struct KhgDecSmem {
     uint32_t mask[(KHG_SUB_WORDS + 1) * KHG_DEC_BLOCK];  // word-major: thread t's word w at [w * 256 + t]; a subsequence
                                                          // that starts inside a staged word reaches into one more
     uint16_t map[MO * KHG_DEC_BLOCK];              // offset-major: thread t's entry for offset o at [o * 256 + t]
-    uint32_t main_arr[KHG_DEC_BLOCK];              // where subsequence t's recording run lands
-    uint32_t next_oo[KHG_DEC_BLOCK];               // ... and the offset it started from (lower ones may still run on)
+    uint32_t main_arr[KHG_DEC_BLOCK];              // where subsequence t's recording run lands | its offset << 8 | 0x8000
+    uint16_t runs[KHG_MAP_THREADS];                // step 2b's work list: subsequence | offset << 8
+    uint32_t scan[KHG_MAP_THREADS / 64];
 };
 
 // Stage the LUT and the workgroup's span of the stream (byte-swapped words) in LDS.
@@ -558,9 +559,7 @@ KHG_DEV void khg_dec_map_body(const KhgDecArgs& a, uint32_t blk, KhgDecSmem<MO>&
     // LL band) a subsequence has one whole-length run per offset, and the workgroups of those stretches last
     // longest -- the launch lasts as long as they do; halving their threads' chains of dependent steps is what
     // shortens it.  The recording run in between is one thread's work (the partner waits at the barrier).
-#define KHG_MAP_THREAD_SETUP                                                                                       \
-        const int t = tid & (KHG_DEC_BLOCK - 1);                                                                   \
-        const uint32_t half = (uint32_t)tid >> 8;                                                                  \
+#define KHG_MAP_SUB_SETUP /* subsequence t of the workgroup */                                                     \
         const uint32_t sub_begin = blk_begin + (uint32_t)t * KHG_SUB_BITS;                                         \
         const uint32_t end = sub_begin + KHG_SUB_BITS < nbits ? sub_begin + KHG_SUB_BITS : nbits;                  \
         const uint32_t lr_of = s0 - sub_begin;            /* lr = pos + lr_of */                                   \
@@ -569,12 +568,20 @@ KHG_DEV void khg_dec_map_body(const KhgDecArgs& a, uint32_t blk, KhgDecSmem<MO>&
         const uint32_t wbase = (uint32_t)t * KHG_SUB_WORDS;  /* first staged word of the subsequence */           \
         uint16_t* map = &sh.map[t];                                                                                \
         uint32_t* mask = &sh.mask[t];                                                                              \
-        (void)half; (void)lr_of; (void)end_lr; (void)nb_lr; (void)wbase; (void)map; (void)mask;
+        (void)lr_of; (void)end_lr; (void)nb_lr; (void)wbase; (void)map; (void)mask;
+#define KHG_MAP_THREAD_SETUP                                                                                       \
+        const int t = tid & (KHG_DEC_BLOCK - 1);                                                                   \
+        const uint32_t half = (uint32_t)tid >> 8;                                                                  \
+        (void)half;                                                                                                \
+        KHG_MAP_SUB_SETUP
 
     // 1. first codeword from every start offset: where does it land?  The offsets lie in the first three words.
+    //    escs: the thread's offsets whose first codeword leaves the first M bits (bit o), kept for step 2b.
+    uint64_t escs[KHG_NSLOT(KHG_MAP_THREADS)];
     KHG_FOR_THREADS(KHG_MAP_THREADS)
     {
         KHG_MAP_THREAD_SETUP
+        uint64_t esc = 0;
         const uint32_t w0 = bits.stage[khg_stage_slot(wbase)], w1 = bits.stage[khg_stage_slot(wbase + 1)],
                        w2 = bits.stage[khg_stage_slot(wbase + 2)], w3 = bits.stage[khg_stage_slot(wbase + 3)];
         for (uint32_t o = half; o < M; o += 2) {
@@ -591,9 +598,11 @@ KHG_DEV void khg_dec_map_body(const KhgDecArgs& a, uint32_t blk, KhgDecSmem<MO>&
                     len = 0;  // the stream ends inside this codeword
                 }
                 if (len) e = khg_map_entry(KHG_OFF_TEMP, o + len);  // landing offset < 2 * 56
+                if (len && o + len >= M) esc |= 1ull << o;
             }
             map[o * KHG_DEC_BLOCK] = e;
         }
+        escs[KHG_SLOT] = esc;
         if (half == 0)
             for (uint32_t w = 0; w <= KHG_SUB_WORDS; ++w) mask[w * KHG_DEC_BLOCK] = 0;
     }
@@ -678,95 +687,113 @@ KHG_DEV void khg_dec_map_body(const KhgDecArgs& a, uint32_t blk, KhgDecSmem<MO>&
                 else main_arr = lr - (s0 + KHG_SUB_BITS);  // behind the subsequence: an overshoot < M
                 map[ro * KHG_DEC_BLOCK] = khg_map_entry(main_arr, n);
             }
-            sh.main_arr[t] = main_arr;
-            sh.next_oo[t] = found ? ro : 0u;  // offsets below this one may still run on
+            // where the recording run lands, and the offset it started from: offsets below that one may still run on
+            sh.main_arr[t] = main_arr | (found ? 0x8000u | (ro << 8) : 0u);
 #ifdef KHG_TIMING
             if (tid == 0) a.blk[blk].pad_[4] = (uint32_t)wall_clock64();
 #endif
         }
     }
     KHG_BARRIER();
-    // 2b. the other runs, split between the subsequence's two threads by the parity of the offset (a thread reads
-    //     and finishes entries of its own parity only)
+    // 2b. the other runs.  How many a subsequence has differs (none to one per residue class), and so does what a
+    //     thread would find among its own offsets; a wave that lets every lane work through its own list lasts as
+    //     long as its longest list and runs mostly empty.  So the workgroup's runs are numbered (a scan over the
+    //     threads' counts), their (subsequence, offset) pairs are listed in LDS, KHG_MAP_THREADS at a time, and every
+    //     thread takes one from the list: a run reads the start marks and writes only its own map entry, so any
+    //     thread can do it.
+    uint32_t rcnt[KHG_NSLOT(KHG_MAP_THREADS)], rbase[KHG_NSLOT(KHG_MAP_THREADS)], rtotal = 0;
     KHG_FOR_THREADS(KHG_MAP_THREADS)
     {
-        KHG_MAP_THREAD_SETUP
-        const uint32_t main_arr = sh.main_arr[t];
-        int oo = (int)sh.next_oo[t];
-        for (;;) {
-            bool found = false;
-            uint32_t ro = 0, lr = 0;
-            while (oo > 0) {
-                --oo;
-                // (An entry of the partner's parity is read and ignored.  Skipping it with a `continue` in front of
-                // the load made ROCm 7.2's compiler produce wrong codeword counts on gfx950; the simulator's build
-                // was right either way.)
-                const uint16_t e0 = map[oo * KHG_DEC_BLOCK];
-                if (((uint32_t)oo & 1u) == half && khg_map_arr(e0) == KHG_OFF_TEMP && khg_map_cnt(e0) >= M) {
-                    found = true;
-                    ro = (uint32_t)oo;
-                    lr = s0 + khg_map_cnt(e0);
-                    break;
-                }
+        const int t = tid & (KHG_DEC_BLOCK - 1);
+        const uint32_t mw = sh.main_arr[t];
+        uint64_t esc = escs[KHG_SLOT];
+        esc = (mw & 0x8000u) ? esc & ((1ull << ((mw >> 8) & 63u)) - 1) : 0ull;  // below the recording run's offset
+        escs[KHG_SLOT] = esc;
+        rcnt[KHG_SLOT] = (uint32_t)__builtin_popcountll(esc);
+    }
+    KHG_WG_EXCL_SCAN_NW(KHG_MAP_THREADS / 64, rbase, rcnt, sh.scan, rtotal)
+    for (uint32_t r0 = 0; r0 < rtotal; r0 += KHG_MAP_THREADS) {
+        if (r0) KHG_BARRIER();  // the list of the pass before has been read
+        KHG_FOR_THREADS(KHG_MAP_THREADS)
+        {
+            const uint32_t t = (uint32_t)tid & (KHG_DEC_BLOCK - 1);
+            uint64_t esc = escs[KHG_SLOT];
+            uint32_t idx = rbase[KHG_SLOT] - r0;  // of the thread's first run in this pass's list (may lie outside)
+            while (esc) {
+                const uint32_t o = 63u - (uint32_t)__builtin_clzll(esc);
+                esc &= ~(1ull << o);
+                if (idx < (uint32_t)KHG_MAP_THREADS) sh.runs[idx] = (uint16_t)(t | (o << 8));
+                ++idx;
             }
-            if (!found) break;
-            uint32_t n = 1, join = 0xFFFFFFFFu;
-            bool dead = false;
-            if (lr < end_lr) {
-                uint32_t j = lr >> 5;
-                uint32_t wa = bits.stage[khg_stage_slot(wbase + j)];
-                for (;;) {
-                    const uint32_t wb = bits.stage[khg_stage_slot(wbase + j + 1)];
-                    const uint32_t mw = mask[j * KHG_DEC_BLOCK];
-                    const uint32_t lim = end_lr < 32u * (j + 1) ? end_lr : 32u * (j + 1);
-                    uint32_t tt, len;
-                    do {
-                        const uint32_t sh_ = lr & 31u;
-                        const uint32_t win = (uint32_t)(((((uint64_t)wa << 32) | wb) << sh_) >> 32);
-                        tt = mw << sh_;  // top bit: a start of the recording run, identical from here on
-                        len = sh.len8[win >> (32 - KHG_LUT_BITS)];
-                        len = (int32_t)tt < 0 ? 0u : len;
-                        lr += len;
-                        n += len ? 1u : 0u;
-                    } while (len != 0 && lr < lim);
-                    if ((int32_t)tt < 0) {
-                        join = lr;
-                        break;
-                    }
-                    if (len == 0) {  // a code beyond the first-level table
-                        int sy;
-                        const uint32_t l2 = khg_decode_one(bits, glut, lut2, left, right, tsym, lr - lr_of, &sy);
-                        if (l2 == 0) {
-                            dead = true;
+        }
+        KHG_BARRIER();
+        KHG_FOR_THREADS(KHG_MAP_THREADS)
+        {
+            if (r0 + (uint32_t)tid < rtotal) {
+                const uint32_t item = sh.runs[tid];
+                const int t = (int)(item & 255u);
+                const uint32_t ro = item >> 8;
+                KHG_MAP_SUB_SETUP
+                const uint32_t main_arr = sh.main_arr[t] & 63u;
+                uint32_t lr = s0 + khg_map_cnt(map[ro * KHG_DEC_BLOCK]);  // where the offset's first codeword lands
+                uint32_t n = 1, join = 0xFFFFFFFFu;
+                bool dead = false;
+                if (lr < end_lr) {
+                    uint32_t j = lr >> 5;
+                    uint32_t wa = bits.stage[khg_stage_slot(wbase + j)];
+                    for (;;) {
+                        const uint32_t wb = bits.stage[khg_stage_slot(wbase + j + 1)];
+                        const uint32_t mw = mask[j * KHG_DEC_BLOCK];
+                        const uint32_t lim = end_lr < 32u * (j + 1) ? end_lr : 32u * (j + 1);
+                        uint32_t tt, len;
+                        do {
+                            const uint32_t sh_ = lr & 31u;
+                            const uint32_t win = (uint32_t)(((((uint64_t)wa << 32) | wb) << sh_) >> 32);
+                            tt = mw << sh_;  // top bit: a start of the recording run, identical from here on
+                            len = sh.len8[win >> (32 - KHG_LUT_BITS)];
+                            len = (int32_t)tt < 0 ? 0u : len;
+                            lr += len;
+                            n += len ? 1u : 0u;
+                        } while (len != 0 && lr < lim);
+                        if ((int32_t)tt < 0) {
+                            join = lr;
                             break;
                         }
-                        lr += l2;
-                        ++n;
+                        if (len == 0) {  // a code beyond the first-level table
+                            int sy;
+                            const uint32_t l2 = khg_decode_one(bits, glut, lut2, left, right, tsym, lr - lr_of, &sy);
+                            if (l2 == 0) {
+                                dead = true;
+                                break;
+                            }
+                            lr += l2;
+                            ++n;
+                        }
+                        if (lr >= end_lr) break;
+                        const uint32_t jn = lr >> 5;
+                        if (jn != j) wa = jn == j + 1 ? wb : bits.stage[khg_stage_slot(wbase + jn)];
+                        j = jn;
                     }
-                    if (lr >= end_lr) break;
-                    const uint32_t jn = lr >> 5;
-                    if (jn != j) wa = jn == j + 1 ? wb : bits.stage[khg_stage_slot(wbase + jn)];
-                    j = jn;
+                    if (!dead && join == 0xFFFFFFFFu && lr > nb_lr) {  // the stream ends inside the last codeword
+                        dead = true;
+                        --n;
+                    }
                 }
-                if (!dead && join == 0xFFFFFFFFu && lr > nb_lr) {  // the stream ends inside the last codeword
-                    dead = true;
-                    --n;
+                uint32_t arr;
+                if (join != 0xFFFFFFFFu) {
+                    const uint32_t wq = join >> 5, bit = 0x80000000u >> (join & 31u);
+                    uint32_t rest = (uint32_t)__builtin_popcount(mask[wq * KHG_DEC_BLOCK] & (bit | (bit - 1)));
+                    for (uint32_t w2 = wq + 1; w2 <= KHG_SUB_WORDS; ++w2)
+                        rest += (uint32_t)__builtin_popcount(mask[w2 * KHG_DEC_BLOCK]);
+                    n += rest;
+                    arr = main_arr;
+                } else if (dead || lr >= nb_lr) {
+                    arr = KHG_OFF_NONE;
+                } else {
+                    arr = lr - (s0 + KHG_SUB_BITS);  // behind the subsequence: an overshoot < M
                 }
+                map[ro * KHG_DEC_BLOCK] = khg_map_entry(arr, n);
             }
-            uint32_t arr;
-            if (join != 0xFFFFFFFFu) {
-                const uint32_t wq = join >> 5, bit = 0x80000000u >> (join & 31u);
-                uint32_t rest = (uint32_t)__builtin_popcount(mask[wq * KHG_DEC_BLOCK] & (bit | (bit - 1)));
-                for (uint32_t w2 = wq + 1; w2 <= KHG_SUB_WORDS; ++w2)
-                    rest += (uint32_t)__builtin_popcount(mask[w2 * KHG_DEC_BLOCK]);
-                n += rest;
-                arr = main_arr;
-            } else if (dead || lr >= nb_lr) {
-                arr = KHG_OFF_NONE;
-            } else {
-                arr = lr - (s0 + KHG_SUB_BITS);  // behind the subsequence: an overshoot < M
-            }
-            map[ro * KHG_DEC_BLOCK] = khg_map_entry(arr, n);
         }
     }
     KHG_BARRIER();
