@@ -1173,10 +1173,13 @@ KHG_DEV void khg_dec_chain_finish_body(const KhgDecArgs& a, int p, uint32_t batc
     }
 }
 
+enum { KHG_WRITE_BUCKETS = 32 };
 struct KhgDecWriteSmem {
     uint32_t lut[KHG_LUT_SIZE];
     uint32_t stage[KHG_STAGE_LDS];
-    uint32_t pre[KHG_DEC_BLOCK + 1];
+    uint32_t pre[KHG_DEC_BLOCK + 1];                 // (start offset << 24) | codewords before subsequence t; [256]: all
+    uint32_t hist[KHG_WRITE_BUCKETS], hbase[KHG_WRITE_BUCKETS];  // subsequences per bucket of codeword counts; before it
+    uint8_t perm[KHG_DEC_BLOCK];                     // the subsequence thread i decodes
 };
 
 // One workgroup = 256 subsequences: every thread looks up its exact start and output position, then
@@ -1203,15 +1206,25 @@ KHG_DEV void khg_dec_write_body(const KhgDecArgs& a, uint32_t blk, KhgDecWriteSm
     const long long tm0 = wall_clock64();
 #endif
     const KhgBitsL bits = khg_dec_stage(a, p, blk_begin, sh);
-    uint32_t offs[KHG_NSLOT(256)];
     KHG_FOR_THREADS(256)
     {
-        const uint32_t w = gw[(uint32_t)tid * M + entry];
-        offs[KHG_SLOT] = w >> 24;
-        sh.pre[tid] = w & 0xFFFFFFu;
+        sh.pre[tid] = gw[(uint32_t)tid * M + entry];  // (start offset << 24) | codewords before the subsequence
         if (tid == 0) sh.pre[KHG_DEC_BLOCK] = a.blk[blk].map[entry] & 0xFFFFFFu;  // codewords of the whole workgroup
+        if (tid < KHG_WRITE_BUCKETS) sh.hist[tid] = 0;
     }
     KHG_BARRIER();
+    // Who decodes what.  A subsequence costs one trip per codeword that is not the 1-bit one, and of those it holds
+    // the more the fewer codewords it has (a stretch of LL symbols: 30 codewords of 8 bits; a stretch of quiet detail:
+    // 200 of them, nearly all one bit).  A wave lasts as long as its costliest lane, so the workgroup's subsequences
+    // are dealt out sorted by their codeword counts (a counting sort in LDS, eight counts to a bucket) instead of in
+    // stream order: at the High preset a wave then takes 22 trips on average instead of 34.
+    uint32_t ranks[KHG_NSLOT(256)];
+    KHG_FOR_THREADS(256)
+    {
+        const uint32_t cnt = (sh.pre[tid + 1] & 0xFFFFFFu) - (sh.pre[tid] & 0xFFFFFFu);
+        const uint32_t key = cnt >> 3 < (uint32_t)KHG_WRITE_BUCKETS - 1 ? cnt >> 3 : (uint32_t)KHG_WRITE_BUCKETS - 1;
+        ranks[KHG_SLOT] = (key << 16) | khg_atomic_add(&sh.hist[key], 1u);
+    }
     // The workgroup's symbols are one contiguous stretch of the plane, and most of them are the plane's 1-bit
     // symbol: the stretch is first filled with it in 16-byte stores by all threads (what a lane would otherwise
     // write run by run, every lane of a wave into a different cache line), then each thread stores only the
@@ -1234,21 +1247,33 @@ KHG_DEV void khg_dec_write_body(const KhgDecArgs& a, uint32_t blk, KhgDecWriteSm
                 for (uint32_t i = a1 + (uint32_t)tid; i < o1; i += 256) base[i] = (int16_t)onesym;
             }
         }
-        KHG_BARRIER();  // the fill is complete (and visible to this workgroup) before single symbols land in it
     }
+    KHG_BARRIER();  // the fill is complete (and visible to this workgroup) before single symbols land in it
     KHG_FOR_THREADS(256)
     {
+        if (tid < KHG_WRITE_BUCKETS) {
+            uint32_t before = 0;
+            for (int k = 0; k < tid; ++k) before += sh.hist[k];
+            sh.hbase[tid] = before;
+        }
+    }
+    KHG_BARRIER();
+    KHG_FOR_THREADS(256) { sh.perm[sh.hbase[ranks[KHG_SLOT] >> 16] + (ranks[KHG_SLOT] & 0xFFFFu)] = (uint8_t)tid; }
+    KHG_BARRIER();
+    KHG_FOR_THREADS(256)
+    {
+        const uint32_t t = sh.perm[tid];  // this thread's subsequence
         // Start and count come from the walk table -- from the map kernel, or, for a file with an index, from the
         // file, which may say anything: a subsequence holds at most one codeword per bit from its start offset on,
         // and a codeword that does not begin inside the subsequence is not this thread's, whatever the count says
         // (so the cursor never leaves the staged span and no thread decodes more than its 256 bits).
-        const uint32_t off = offs[KHG_SLOT];
-        uint32_t cnt = sh.pre[tid + 1] - sh.pre[tid];
+        const uint32_t off = sh.pre[t] >> 24;
+        uint32_t cnt = (sh.pre[t + 1] & 0xFFFFFFu) - (sh.pre[t] & 0xFFFFFFu);
         if (off < KHG_SUB_BITS && cnt > KHG_SUB_BITS - off) cnt = KHG_SUB_BITS - off;
         if (off < KHG_SUB_BITS && cnt) {
-            const uint32_t o = a.blk[blk].out + sh.pre[tid];
-            const uint32_t pos = blk_begin + (uint32_t)tid * KHG_SUB_BITS + off;
-            const uint32_t sub_end = blk_begin + ((uint32_t)tid + 1) * KHG_SUB_BITS;
+            const uint32_t o = a.blk[blk].out + (sh.pre[t] & 0xFFFFFFu);
+            const uint32_t pos = blk_begin + t * KHG_SUB_BITS + off;
+            const uint32_t sub_end = blk_begin + (t + 1) * KHG_SUB_BITS;
             const uint32_t lim = a.n[p];
             const uint32_t todo = o >= lim ? 0 : (cnt < lim - o ? cnt : lim - o);  // never store past the plane
             int16_t* const base = a.sym[p];  // 16-byte aligned (workspace)
