@@ -550,15 +550,16 @@ KHG_DEV void khg_dec_map_body(const KhgDecArgs& a, uint32_t blk, KhgDecSmem<MO>&
     // A subsequence is walked one 32-bit word of the staged stream at a time: the word, its successor and the
     // word's start marks sit in registers while the codewords that begin in it are stepped over, so a step costs one
     // LDS access (the code length under the bit window) instead of four (two stream words, the mark word, the
-    // length).  The LDS pipe, not its latency, is what this kernel waits for.  Positions are kept relative to the
+    // length).  Positions are kept relative to the
     // first staged word of the subsequence: lr = (position in the subsequence) + s0, the same s0 < 32 for every
     // thread (subsequences are 256 bits, a whole number of words, apart).
     const uint32_t s0 = (blk_begin - bits.bias) & 31u;
     // Two threads per subsequence: thread t and thread 256 + t share subsequence t's columns of `map` and `mask`
-    // and split its start offsets by parity.  Where runs never rejoin (stretches of near-equal code lengths: the
-    // LL band) a subsequence has one whole-length run per offset, and the workgroups of those stretches last
-    // longest -- the launch lasts as long as they do; halving their threads' chains of dependent steps is what
-    // shortens it.  The recording run in between is one thread's work (the partner waits at the barrier).
+    // and split its start offsets by parity for the first codewords; the recording run is one thread's work (the
+    // partner waits at the barrier), and the runs behind it are dealt out to all the workgroup's threads (step 2b).
+    // Where runs never rejoin (stretches of near-equal code lengths: the LL band) a subsequence has one whole-length
+    // run per offset, and the workgroups of those stretches last longest -- the launch lasts as long as they do;
+    // spreading their runs over twice the threads is what shortens it.
 #define KHG_MAP_SUB_SETUP /* subsequence t of the workgroup */                                                     \
         const uint32_t sub_begin = blk_begin + (uint32_t)t * KHG_SUB_BITS;                                         \
         const uint32_t end = sub_begin + KHG_SUB_BITS < nbits ? sub_begin + KHG_SUB_BITS : nbits;                  \
