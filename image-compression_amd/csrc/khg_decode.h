@@ -25,7 +25,7 @@
 #include "khg_common.h"
 #include "khg_huffman.h"
 
-// Bits per subsequence, a build-time choice (power of two, 128..512).  Measured on 8K frames against 512: 256 halves
+// Bits per subsequence, a build-time choice (256 or 512).  Measured on 8K frames against 512: 256 halves
 // the serial chains per lane in the stretches that need one run per residue class (map 290 -> 157 us, write 73 ->
 // 55 us for one frame alone) at the price of twice the first-codeword work, workgroup records and chain steps
 // (35 -> 66 us, one lane); in the pipelined batch it decodes 4 % more frames per second.
@@ -34,7 +34,7 @@
 #endif
 
 enum {
-    KHG_SUB_BITS = KHG_SUB_BITS_CFG,  // bits per subsequence (a power of two >= 128; build-time choice)
+    KHG_SUB_BITS = KHG_SUB_BITS_CFG,  // bits per subsequence (build-time choice)
     KHG_SUB_WORDS = KHG_SUB_BITS / 32,
     KHG_DEC_BLOCK = 256,      // subsequences per workgroup
     KHG_BLK_BITS = KHG_SUB_BITS * KHG_DEC_BLOCK,
@@ -48,6 +48,10 @@ enum {
     KHG_OFF_TEMP = 62,        // map entry not final yet: the count field holds the landing offset
     KHG_OFF_NONE = 63         // no codeword starts from here on (the stream has ended)
 };
+
+// (128-bit subsequences decode streams with codes of up to 32 bits and fail the test with 44-bit codes: a start
+// offset plus the longest code must stay well inside a subsequence.)
+static_assert(KHG_SUB_BITS == 256 || KHG_SUB_BITS == 512, "subsequences of 256 or 512 bits");
 
 // Decoder limit on a plane's stream: 16 bits per symbol on average.  A Huffman code built from the
 // stored counts averages below log2(K) + 1 <= 15 bits when the stream follows those counts, as every
@@ -453,10 +457,7 @@ KHG_DEV uint32_t khg_decode_one(const KhgBitsL& b, const uint32_t* lut, const ui
 // LDS of the map kernel.  MO = start offsets it has room for: with 32 (codes up to 32 bits, i.e. nearly every
 // stream) a workgroup needs 40 488 bytes and four fit on a CU (163 840 bytes); streams with longer codes are handled by the
 // KHG_MAXOFF instantiation (three per CU).  A launch of either does nothing for planes that belong to the other.
-#ifndef KHG_MAP_THREADS_CFG
-#define KHG_MAP_THREADS_CFG (2 * KHG_DEC_BLOCK)
-#endif
-enum { KHG_MAP_SMALL = 32, KHG_MAP_THREADS = KHG_MAP_THREADS_CFG };  // two threads per subsequence (khg_dec_map_body)
+enum { KHG_MAP_SMALL = 32, KHG_MAP_THREADS = 2 * KHG_DEC_BLOCK };  // two threads per subsequence (khg_dec_map_body)
 template <int MO>
 struct KhgDecSmem {
     uint8_t len8[KHG_LUT_SIZE];                    // see khg_dec_stage_lens
