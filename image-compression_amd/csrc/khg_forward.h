@@ -605,18 +605,12 @@ KHG_DEV bool khg_col_emit(const KhgFwdArgs& a, const KhgFwdPlane& pl, uint32_t* 
                 v = 0;  // stored and counted as a zero; the job fails with KHG_ERR_RANGE
             }
             const uint32_t raster = (so + 2u * (uint32_t)p) >> 1;
-#ifdef KHG_EXP_NOLLHIST
-            if (v == 12345) {
-#else
             if ((unsigned)(v + a.lhist / 2) < (unsigned)a.lhist) {
-#endif
                 khg_lds_add(&lcnt[v + LHIST / 2], 1u);
                 khg_lds_min(&lfirst[v + LHIST / 2], raster);
             } else {
-#ifndef KHG_EXP_NOLLHIST
                 khg_atomic_add(&pl.hist_cnt[v + KHG_SYM_BIAS], 1u);
                 khg_atomic_min(&pl.hist_first[v + KHG_SYM_BIAS], raster);
-#endif
             }
             q[0][p] = v;
         }
@@ -781,15 +775,7 @@ KHG_DEV void khg_fwd_wg_body(const KhgFwdArgs& a, const KhgFwdPlane* pls, int wg
     KHG_FWD_STAMP_HERE(6);
 
     // Row pairs k0-2 .. k1+1 are fed; the column pipeline hands back pair j-2 when pair j goes in.
-#if !defined(KHG_SIM) && defined(KHG_FWD_UNROLL2)
-    // Developer option: an even number of trips (the one too many finishes row pair k1, which is not output), two per
-    // pass of the compiled loop, so that the column states return to their registers every second trip instead of
-    // being copied back at the end of every one (16 64-bit moves per trip and sample pair).  Measured: twice the
-    // code, no gain.
-    const int jend = k1 + 1 + ((k1 - k0) & 1);
-#else
     const int jend = k1 + 1;
-#endif
 #ifndef KHG_SIM
     // a wave whose strip lies beyond the plane has nothing to do until the workgroup's last barrier
     const bool idle = SP * (swg * KHG_WG_STRIPS + KHG_UNIFORM((int)(threadIdx.x >> 6))) >= np;
@@ -800,9 +786,6 @@ KHG_DEV void khg_fwd_wg_body(const KhgFwdArgs& a, const KhgFwdPlane* pls, int wg
         // source rows of the trip PF ahead (the same for every thread)
         uint32_t noa, nob;
         khg_fwd_row_offsets<SRC>(a, g, rw, j + PF, noa, nob);
-#ifdef KHG_EXP_FAKELOAD  // developer experiment: every trip reads the same two rows
-        noa = 0; nob = 0;
-#endif
         KHG_FOR_THREADS(256)
         {
             KHG_UNROLL
@@ -914,34 +897,17 @@ KHG_DEV void khg_fwd_wg_body(const KhgFwdArgs& a, const KhgFwdPlane* pls, int wg
                 // behind the buffer (two pairs per lane: an even pair of an even-pitched buffer, one aligned word /
                 // 16 bytes).
                 if (LEVEL == 1) {
-#ifdef KHG_EXP_NOSTORE  // developer experiment: every store goes to the dump area
-                    const uint32_t o = lld[n] + (uint32_t)(8 * LP * tid);
-#else
                     const uint32_t o = out ? llo[KHG_SLOT] : lld[n] + (uint32_t)(8 * LP * tid);
-#endif
-#ifdef KHG_EXP_NTSTORE
-                    for (int p = 0; p < LP; ++p) __builtin_nontemporal_store(llv[p], (double*)(llb[n] + o) + p);
-#else
                     __builtin_memcpy(KHG_ASSUME_ALIGNED(llb[n] + o, LP == 2 ? 16 : 8), llv, sizeof llv);
-#endif
                 }
                 KHG_UNROLL
                 for (int s = 0; s < SM::NBAND; ++s) {
                     const int b4 = s + 4 - SM::NBAND;
                     const uint32_t boff = b4 == 0 ? 0u : b4 == 1 ? right : b4 == 2 ? down : down + right;
-#ifdef KHG_EXP_NOSTORE
-                    const uint32_t o = symd[n] + (uint32_t)(1024 * s + (LP == 2 ? 4 : 2) * tid) + 0 * boff;
-#else
                     const uint32_t o = syms ? symo[KHG_SLOT] + boff : symd[n] + (uint32_t)(1024 * s + (LP == 2 ? 4 : 2) * tid);
-#endif
                     char* at = symb[n] + o;
-#ifdef KHG_EXP_NTSTORE
-                    if (LP == 2) __builtin_nontemporal_store(words[s], (uint32_t*)at);
-                    else __builtin_nontemporal_store((int16_t)words[s], (int16_t*)at);
-#else
                     if (LP == 2) __builtin_memcpy(KHG_ASSUME_ALIGNED(at, 4), &words[s], 4);
                     else *(int16_t*)at = (int16_t)words[s];
-#endif
                 }
             }
             symo[KHG_SLOT] += sym_step;
@@ -966,16 +932,8 @@ KHG_DEV void khg_fwd_wg_body(const KhgFwdArgs& a, const KhgFwdPlane* pls, int wg
             }
         }
     };
-#if !defined(KHG_SIM) && defined(KHG_FWD_UNROLL2)
-    if (!idle)
-        for (int j = k0 - 2; j <= jend; j += 2) {
-            trip(j);
-            trip(j + 1);
-        }
-#else
     if (!idle)
         for (int j = k0 - 2; j <= jend; ++j) trip(j);
-#endif
 
     KHG_FWD_STAMP_HERE(7);
     KHG_FOR_THREADS(256)
@@ -1010,9 +968,7 @@ enum { KHG_FWD_RGB = 0, KHG_FWD_PLANES1 = 1, KHG_FWD_PLANES2 = 2, KHG_FWD_BGR = 
 template <int KIND, int LP, int LPC, bool TAP>
 KHG_DEV void khg_fwd_launch_body(const KhgFwdArgs& a, int wg, KhgFwdSmemAny& sh)
 {
-#ifndef KHG_EXP_NOREMAP
     wg = khg_xcd_remap(wg, a.nwg);
-#endif
     KHG_FWD_STAMP(wg, 0, (uint32_t)wall_clock64());
     KHG_FWD_STAMP(wg, 2, __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)));  // HW_ID
     KHG_FWD_STAMP(wg, 3, __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)));  // XCC_ID
