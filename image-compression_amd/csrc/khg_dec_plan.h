@@ -85,8 +85,8 @@ static inline int khg_tile_need_ranges_impl(int rows, int cols, KhgTile t, int c
 #define KHG_INV_SLOTS 1024
 #endif
 
-// Plane of colour component comp at level 2 (into the LL buffer) or level 1 (into the component's f64 plane, or
-// dst when given) of an inverse launch, without its grid.
+// Plane of colour component comp at level 2 (into the LL buffer) or level 1 (into dst: the caller's f64 plane, or
+// none where the launch converts to RGB) of an inverse launch, without its grid.
 // Tiles: every rank decodes the whole symbol planes, so a tile only restricts the rows it reconstructs: its band at
 // level 1, and at level 2 that band of the LL quadrant widened by 4 rows (level 1 reads two row pairs beyond).
 static inline void khg_inv_plane(KhgInvPlane* pl, const KhgWorkspace& ws, const KhgDecWorkspace& dws, int rows, int cols,
@@ -104,7 +104,7 @@ static inline void khg_inv_plane(KhgInvPlane* pl, const KhgWorkspace& ws, const 
         pl->dst_pitch = pcol / 2;
     } else {
         pl->ph = prow; pl->pw = pcol;
-        pl->dst = dst ? dst : dws.plane[comp];  // unused for luma in the RGB variant
+        pl->dst = dst;
         pl->dst_pitch = pcol;
     }
     for (int lvl = 0; lvl < 3; ++lvl) khg_make_quant(rows, cols, lvl, comp != 0, &pl->q[lvl]);
@@ -120,17 +120,14 @@ static inline void khg_inv_plane(KhgInvPlane* pl, const KhgWorkspace& ws, const 
     }
 }
 
-// An inverse launch over planes comp0 .. comp0 + n - 1 at `level` (KHG_INV_PLANES2 / KHG_INV_PLANES1), or the luma
-// plane into the RGB image (KHG_INV_RGB: n = 1, r / g / b set by the caller).  dst: optional outputs of the level-1
-// planes (null: the workspace's).
+// An inverse launch over planes comp0 .. comp0 + n - 1 at `level` (KHG_INV_PLANES2 / KHG_INV_PLANES1; dst: the
+// outputs of the level-1 planes), or the grid of the fused launch (khg_inv_args_fused).
 static inline KhgInvArgs khg_inv_args(const KhgWorkspace& ws, const KhgDecWorkspace& dws, int rows, int cols, int comp0,
                                       int n, int level, KhgTile tile = KhgTile{0, 1}, double* const dst[3] = nullptr)
 {
     KhgInvArgs a;
     memset(&a, 0, sizeof a);
     a.hdr = dws.hdr;
-    a.cb = dws.plane[1];
-    a.cr = dws.plane[2];
     a.out_row0 = khg_tile_row0(rows, tile);
     a.nplanes = n;
     KhgGridGroup g[3];

@@ -86,7 +86,6 @@ struct KhgBlkInfo {
 };
 
 struct KhgDecWorkspace {
-    double* plane[3];   // reconstructed Cb / Cr (f64) in [1], [2]; [0] is a stub (luma goes straight to RGB)
     uint32_t* lut;      // [3][KHG_LUT_SIZE] first-level decode tables
     uint32_t* lut2;     // [3][KHG_LUT_SIZE][KHG_LUT2_SIZE] second-level tables (only rows of missing prefixes are filled)
     KhgBlkInfo* blk;    // per workgroup, planes concatenated
@@ -95,7 +94,7 @@ struct KhgDecWorkspace {
 };
 
 struct KhgDecWorkspaceSizes {
-    size_t plane[3], lut, lut2, blk, walk;
+    size_t lut, lut2, blk, walk;
 };
 
 static inline uint32_t khg_max_blocks(uint64_t nsym)
@@ -139,8 +138,6 @@ KHG_HOST_DEV uint32_t khg_part_begin(uint32_t nb, uint32_t r, uint32_t n) { retu
 static inline void khg_dec_workspace_sizes(int rows, int cols, KhgDecWorkspaceSizes* s)
 {
     size_t ny = (size_t)rows * cols, nc = ny / 4;
-    s->plane[0] = 64;  // the luma plane is converted to RGB as it is produced and never stored
-    s->plane[1] = s->plane[2] = nc * sizeof(double);
     size_t blocks = (size_t)khg_max_blocks(ny) + 2 * (size_t)khg_max_blocks(nc);
     s->lut = 3 * (size_t)KHG_LUT_SIZE * sizeof(uint32_t);
     s->lut2 = 3 * (size_t)KHG_LUT_SIZE * KHG_LUT2_SIZE * sizeof(uint32_t);

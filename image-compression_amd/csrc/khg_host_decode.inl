@@ -41,21 +41,11 @@ static void khg_enqueue_inverse(khg_ctx* c, int rows, int cols, uint8_t* d_r, ui
         const KhgInvArgs a = khg_inv_args(c->ws, c->dws, rows, cols, 0, 3, 1, tile, ycbcr);
         hipLaunchKernelGGL((khg_inv_kernel<KHG_INV_PLANES1>), dim3(a.nwg), dim3(256), 0, st, a);
     } else {  // level 1 of Y, Cb and Cr with Colorspace.h:25-36 + Main.cpp:307-315, one launch
-#ifdef KHG_INV_UNFUSED  // developer build: Cb and Cr into f64 planes first, then the luma launch that reads them
-        const KhgInvArgs ac = khg_inv_args(c->ws, c->dws, rows, cols, 1, 2, 1, tile);
-        hipLaunchKernelGGL((khg_inv_kernel<KHG_INV_PLANES1>), dim3(ac.nwg), dim3(256), 0, st, ac);
-        KhgInvArgs ay = khg_inv_args(c->ws, c->dws, rows, cols, 0, 1, 1, tile);
-        ay.r = d_r; ay.g = d_g; ay.b = d_b;
-        ay.bgr_stride = bgr_stride;
-        if (bgr_stride) hipLaunchKernelGGL((khg_inv_kernel<KHG_INV_BGR>), dim3(ay.nwg), dim3(256), 0, st, ay);
-        else hipLaunchKernelGGL((khg_inv_kernel<KHG_INV_RGB>), dim3(ay.nwg), dim3(256), 0, st, ay);
-#else
         KhgInvArgs ay = khg_inv_args_fused(c->ws, c->dws, rows, cols, tile);
         ay.r = d_r; ay.g = d_g; ay.b = d_b;
         ay.bgr_stride = bgr_stride;
         if (bgr_stride) hipLaunchKernelGGL((khg_inv_kernel<KHG_INV_BGR_FUSED>), dim3(ay.nwg), dim3(256), 0, st, ay);
         else hipLaunchKernelGGL((khg_inv_kernel<KHG_INV_RGB_FUSED>), dim3(ay.nwg), dim3(256), 0, st, ay);
-#endif
     }
 }
 

@@ -9,9 +9,9 @@
 //            lifting pipelines held in registers, which hand back two finished natural-order rows;
 //   rows   : each of the two rows is inverse-lifted across the lanes, the neighbouring pair's value coming from
 //            the neighbouring lane by a DPP wave shift (four exchanges per row, two halo pairs per strip side), and
-//            the lane's two samples are stored -- or, for the luma plane at level 1, combined with the finished
+//            the lane's two samples are stored -- or, in the fused level-1 launch, combined with the finished
 //            chroma sample of this position (one Cb, one Cr per lane and trip: Colorspace.h:31-33 reads them at
-//            [y/2][x/2]) into RGB and written as u8, so the f64 luma plane never exists in memory.
+//            [y/2][x/2]) into RGB and written as u8, so the f64 planes never exist in memory.
 #pragma once
 #include "khg_common.h"
 #include "khg_decode.h"
@@ -28,7 +28,7 @@ struct KhgInvPlane {
     const double* ll;     // level 1: the LL quadrant (output of the level-2 inverse)
     int ll_pitch;
     int ph, pw;           // rows, cols of this transform
-    double* dst;          // natural-order output, ph x pw (unused by the RGB variant)
+    double* dst;          // natural-order output, ph x pw (unused by the fused launch)
     int dst_pitch;
     int row_begin, row_end;  // output rows this launch produces (even; the whole plane, or one tile's band)
     int seg_rows;         // output rows of the tallest workgroup segment (even; see khg_segment_rows)
@@ -42,10 +42,8 @@ struct KhgInvArgs {
     const KhgDecHeader* hdr;  // supplies the preset (lvl) and the go/no-go flag
     int nplanes;
     int nwg;
-    int out_row0;             // RGB variant: image row held by the first row of r/g/b (0 for a whole image)
-    // RGB variant (level 1 of the luma plane): the finished chroma planes and the output image
-    const double *cb, *cr;    // (ph/2) x (pw/2)
-    uint8_t *r, *g, *b;       // pitch pw
+    int out_row0;             // fused launch: image row held by the first row of r/g/b (0 for a whole image)
+    uint8_t *r, *g, *b;       // fused launch: the output image, pitch pw
     // BMP variant: the output is a 24-bit BMP pixel array instead (KhuGleSignal.cpp:285-293: B, G, R per pixel, image
     // row y at row ph - 1 - y of the array); r = its first byte, bgr_stride = bytes per row of the array
     size_t bgr_stride;
@@ -95,10 +93,10 @@ KHG_DEV void khg_inv_step(KhgILift& st, double lo, double hi, double& xe, double
 }
 
 // Raw inputs of one lane for one trip: the symbols at (ke, p), (ke, hw+p), (ko, p), (ko, hw+p) -- at level 1 the
-// first one is the LL sample instead -- and, in the RGB variant, the chroma sample of the rows the trip finishes.
+// first one is the LL sample instead.
 struct KhgInvRaw {
     int q[4];
-    double ll, cb, cr;
+    double ll;
 };
 
 KHG_DEV uint32_t khg_clamp_u8(double v)
@@ -126,18 +124,16 @@ KHG_DEV void khg_rgb_pair(double y0, double y1, double Cb, double Cr, uint32_t r
     rgb[2] = khg_clamp_u8(y0 * 1 + bb) | (khg_clamp_u8(y1 * 1 + bb) << 8);
 }
 
-// Where the finished samples of a level-1 transform go: an f64 plane, the planar u8 image, or a BMP pixel array.
-enum { KHG_OUT_PLANE = 0, KHG_OUT_RGB = 1, KHG_OUT_BGR = 2 };
+// Where the fused level-1 launch puts its pixels: the planar u8 image or a BMP pixel array.
+enum { KHG_OUT_RGB = 1, KHG_OUT_BGR = 2 };
 
 KHG_DEV void khg_st16(uint8_t* p, uint32_t v) { const uint16_t h = (uint16_t)v; __builtin_memcpy(p, &h, 2); }
 
-// One workgroup: KHG_WG_STRIPS adjacent strips (one per wave) over one segment of output rows of plane pl.
-// OUT != KHG_OUT_PLANE (level 1 of the luma plane only): the row phase does not store the luma samples but combines
-// them with the already reconstructed chroma planes and writes the u8 image.
-template <int LEVEL, int OUT>
+// One workgroup: KHG_WG_STRIPS adjacent strips (one per wave) over one segment of output rows of plane pl, into
+// its f64 output.
+template <int LEVEL>
 KHG_DEV void khg_inv_wg_body(const KhgInvArgs& a, const KhgInvPlane& pl, int wgl, KhgInvSmem<LEVEL>& sh)
 {
-    constexpr bool RGB = OUT != KHG_OUT_PLANE;
     typedef KhgInvSmem<LEVEL> SM;
     if (!a.hdr->ok) return;
     const int lvl = a.hdr->lvl;
@@ -164,7 +160,7 @@ KHG_DEV void khg_inv_wg_body(const KhgInvArgs& a, const KhgInvPlane& pl, int wgl
     int uL[KHG_NSLOT(256)], uH[KHG_NSLOT(256)];  // their offsets in the workgroup's divisor diagonals
     bool outl[KHG_NSLOT(256)];  // the lane outputs its pair
     double LO[2][KHG_NSLOT(256)], HI[2][KHG_NSLOT(256)], S1[2][KHG_NSLOT(256)], D1[2][KHG_NSLOT(256)],
-        S0[2][KHG_NSLOT(256)], X[2][KHG_NSLOT(256)], CB[KHG_NSLOT(256)], CR[KHG_NSLOT(256)];
+        S0[2][KHG_NSLOT(256)], X[2][KHG_NSLOT(256)];
 
     // Packed row indices of trip j: low-pass row ke, high-pass row ko (whole-sample reflection of the natural rows
     // 2j and 2j+1 at the plane's top and bottom).
@@ -178,7 +174,7 @@ KHG_DEV void khg_inv_wg_body(const KhgInvArgs& a, const KhgInvPlane& pl, int wgl
         const int p = v0 - 2 + lane;
         outl[KHG_SLOT] = p >= v0 && p < v1;  // a wave beyond the last strip loads and computes without output
         pairs[KHG_SLOT] = p < v0 ? v0 : (p > v0 + KHG_STRIP_PAIRS - 1 ? v0 + KHG_STRIP_PAIRS - 1 : p);
-        if (pairs[KHG_SLOT] > np - 1) pairs[KHG_SLOT] = np - 1;  // it also addresses the chroma sample every lane loads
+        if (pairs[KHG_SLOT] > np - 1) pairs[KHG_SLOT] = np - 1;
         colsL[KHG_SLOT] = khg_reflect(2 * p, pl.pw) >> 1;
         colsH[KHG_SLOT] = khg_reflect(2 * p + 1, pl.pw) >> 1;
         const int umax = KHG_WG_STRIPS * KHG_STRIP_PAIRS + 3;  // lanes beyond the plane: any entry of the table
@@ -202,7 +198,7 @@ KHG_DEV void khg_inv_wg_body(const KhgInvArgs& a, const KhgInvPlane& pl, int wgl
     }
     KHG_BARRIER();
 
-    // Loads of trip j into raw (all four positions, and the chroma sample of the rows trip j finishes).
+    // Loads of trip j into raw (all four positions).
 #define KHG_INV_FETCH(raw, j)                                                                               \
     {                                                                                                       \
         const int ke_ = KHG_INV_KE(j), ko_ = hh + KHG_INV_KO(j);                                            \
@@ -218,13 +214,6 @@ KHG_DEV void khg_inv_wg_body(const KhgInvArgs& a, const KhgInvPlane& pl, int wgl
         (raw).q[1] = pl.sym[oe_ + ch_];                                                                     \
         (raw).q[2] = pl.sym[oo_ + cl_];                                                                     \
         (raw).q[3] = pl.sym[oo_ + ch_];                                                                     \
-        if (RGB) {                                                                                          \
-            int m_ = (j) - 2;                                                                               \
-            m_ = m_ < 0 ? 0 : (m_ > hh - 1 ? hh - 1 : m_);                                                  \
-            const uint32_t oc_ = (uint32_t)m_ * (uint32_t)hw + (uint32_t)pairs[KHG_SLOT];                   \
-            (raw).cb = a.cb[oc_];                                                                           \
-            (raw).cr = a.cr[oc_];                                                                           \
-        }                                                                                                   \
     }
 
     KHG_FOR_THREADS(256) { KHG_INV_FETCH(raws[KHG_SLOT], k0 - 2) }
@@ -258,10 +247,6 @@ KHG_DEV void khg_inv_wg_body(const KhgInvArgs& a, const KhgInvPlane& pl, int wgl
             for (int rr = 0; rr < 2; ++rr) {
                 LO[rr][KHG_SLOT] = khg_inv_unscale_low(LO[rr][KHG_SLOT]);
                 HI[rr][KHG_SLOT] = khg_inv_unscale_high(HI[rr][KHG_SLOT]);
-            }
-            if (RGB) {  // this trip's chroma sample (raws now holds the next trip's)
-                CB[KHG_SLOT] = raw.cb;
-                CR[KHG_SLOT] = raw.cr;
             }
         }
         // s1[p] = s[p] + C1 * (d[p-1] + d[p])
@@ -304,30 +289,11 @@ KHG_DEV void khg_inv_wg_body(const KhgInvArgs& a, const KhgInvPlane& pl, int wgl
                     xe[rr] = S0[rr][KHG_SLOT];
                     xo[rr] = D1[rr][KHG_SLOT] + KHG_C4 * (S0[rr][KHG_SLOT] + X[rr][KHG_SLOT]);
                 }
-                if (RGB) {
-                    KHG_UNROLL
-                    for (int rr = 0; rr < 2; ++rr) {
-                        uint32_t rgb[3];
-                        khg_rgb_pair(xe[rr], xo[rr], CB[KHG_SLOT], CR[KHG_SLOT], rgb);
-                        if (OUT == KHG_OUT_BGR) {  // B0 G0 R0 B1 G1 R1, rows bottom-up
-                            uint8_t* px = a.r + (size_t)(pl.ph - 1 - (2 * m + rr)) * a.bgr_stride + 6u * (uint32_t)pair;
-                            khg_st16(px, (rgb[2] & 255u) | ((rgb[1] & 255u) << 8));
-                            khg_st16(px + 2, (rgb[0] & 255u) | (rgb[2] & 0xFF00u));
-                            khg_st16(px + 4, (rgb[1] >> 8) | (rgb[0] & 0xFF00u));
-                        } else {
-                            const uint32_t o = (uint32_t)(2 * m + rr - a.out_row0) * (uint32_t)pl.pw + 2u * (uint32_t)pair;
-                            khg_st16(a.r + o, rgb[0]);
-                            khg_st16(a.g + o, rgb[1]);
-                            khg_st16(a.b + o, rgb[2]);
-                        }
-                    }
-                } else {
-                    KHG_UNROLL
-                    for (int rr = 0; rr < 2; ++rr) {
-                        double* out = pl.dst + ((uint32_t)(2 * m + rr) * (uint32_t)pl.dst_pitch + 2u * (uint32_t)pair);
-                        const double v[2] = {xe[rr], xo[rr]};
-                        __builtin_memcpy(out, v, 16);
-                    }
+                KHG_UNROLL
+                for (int rr = 0; rr < 2; ++rr) {
+                    double* out = pl.dst + ((uint32_t)(2 * m + rr) * (uint32_t)pl.dst_pitch + 2u * (uint32_t)pair);
+                    const double v[2] = {xe[rr], xo[rr]};
+                    __builtin_memcpy(out, v, 16);
                 }
             }
         }
@@ -411,7 +377,6 @@ KHG_DEV void khg_istrip_fetch(KhgInvStrip& st, int slot, const KhgInvGeo& g, int
     r.q[1] = sym[oe + ch];
     r.q[2] = sym[oo + cl];
     r.q[3] = sym[oo + ch];
-    r.cb = r.cr = 0.0;
     st.raw[slot] = r;
 }
 
@@ -567,10 +532,10 @@ KHG_DEV void khg_inv_fused_wg_body(const KhgInvArgs& a, int wgl, KhgInvFusedSmem
     }
 }
 
-// Launch kinds: level 2 of the three components into their LL buffers; level 1 of planes into f64 planes (Cb and
-// Cr, or all three for the plane outputs of DecompressImage); level 1 of the luma plane into the RGB image or into
-// a BMP pixel array.
-enum { KHG_INV_PLANES2 = 0, KHG_INV_PLANES1 = 1, KHG_INV_RGB = 2, KHG_INV_BGR = 3, KHG_INV_RGB_FUSED = 4, KHG_INV_BGR_FUSED = 5 };
+// Launch kinds: level 2 of the three components into their LL buffers; level 1 of the three components into f64
+// planes (the plane outputs of DecompressImage); level 1 of the three components and the colour conversion into the
+// RGB image or into a BMP pixel array.  (2 and 3 were the luma-only launches the fused ones replaced.)
+enum { KHG_INV_PLANES2 = 0, KHG_INV_PLANES1 = 1, KHG_INV_RGB_FUSED = 4, KHG_INV_BGR_FUSED = 5 };
 union KhgInvSmemAny {
     KhgInvSmem<1> l1;
     KhgInvSmem<2> l2;
@@ -582,10 +547,8 @@ KHG_DEV void khg_inv_launch_body(const KhgInvArgs& a, int wg, KhgInvSmemAny& sh)
 {
     int p = 0;
     while (p + 1 < a.nplanes && wg >= a.pl[p + 1].wg0) ++p;
-    if constexpr (KIND == KHG_INV_PLANES2) khg_inv_wg_body<2, KHG_OUT_PLANE>(a, a.pl[p], wg - a.pl[p].wg0, sh.l2);
-    else if constexpr (KIND == KHG_INV_PLANES1) khg_inv_wg_body<1, KHG_OUT_PLANE>(a, a.pl[p], wg - a.pl[p].wg0, sh.l1);
-    else if constexpr (KIND == KHG_INV_RGB) khg_inv_wg_body<1, KHG_OUT_RGB>(a, a.pl[p], wg - a.pl[p].wg0, sh.l1);
-    else if constexpr (KIND == KHG_INV_BGR) khg_inv_wg_body<1, KHG_OUT_BGR>(a, a.pl[p], wg - a.pl[p].wg0, sh.l1);
+    if constexpr (KIND == KHG_INV_PLANES2) khg_inv_wg_body<2>(a, a.pl[p], wg - a.pl[p].wg0, sh.l2);
+    else if constexpr (KIND == KHG_INV_PLANES1) khg_inv_wg_body<1>(a, a.pl[p], wg - a.pl[p].wg0, sh.l1);
     else if constexpr (KIND == KHG_INV_RGB_FUSED) khg_inv_fused_wg_body<KHG_OUT_RGB>(a, wg, sh.f);
     else khg_inv_fused_wg_body<KHG_OUT_BGR>(a, wg, sh.f);
 }

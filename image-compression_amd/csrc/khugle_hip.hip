@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void khg_dec_write_kernel(KhgDecArgs a)
 }
 
 // KIND: KHG_INV_PLANES2 (level 2 of the three components), KHG_INV_PLANES1 (level 1 into f64 planes),
-// KHG_INV_RGB / KHG_INV_BGR (level 1 of the luma plane into the planar RGB image / into a BMP pixel array).
+// KHG_INV_RGB_FUSED / KHG_INV_BGR_FUSED (level 1 of the three components into the planar RGB image / a BMP pixel array).
 template <int KIND>
 __global__ __launch_bounds__(256) void khg_inv_kernel(KhgInvArgs a)
 {
@@ -376,8 +376,6 @@ extern "C" int khg_ctx_create(int device, int max_rows, int max_cols, khg_ctx** 
     size_t o_hc = take(s.hist), o_hf = take(s.hist), o_tc = take(s.tab), o_ts = take(s.tab), o_tk = take(64);
     size_t o_ct = take(s.codetab), o_bs = take(s.big_scratch), o_tl = take(s.tree), o_tr = take(s.tree), o_troot = take(64);
     size_t o_cb = take(s.chunk_bits), o_co = take(s.chunk_off), o_ch = take(s.chain), o_res = take(sizeof(KhgResult));
-    size_t o_plane[3];
-    for (int p = 0; p < 3; ++p) o_plane[p] = take(ds.plane[p]);
     size_t o_lut = take(ds.lut), o_lut2 = take(ds.lut2), o_blk = take(ds.blk), o_walk = take(ds.walk), o_hdr = take(sizeof(KhgDecHeader));
     size_t o_ssim = take(nblk * sizeof(double)), o_sse = take(64), o_mean = take(64);
     c->slab_bytes = total;
@@ -391,7 +389,6 @@ extern "C" int khg_ctx_create(int device, int max_rows, int max_cols, khg_ctx** 
     c->ws.chunk_bits = (uint32_t*)(base + o_cb); c->ws.chunk_off = (uint64_t*)(base + o_co);
     c->ws.chain = (uint64_t*)(base + o_ch);
     c->ws.res = (KhgResult*)(base + o_res);
-    for (int p = 0; p < 3; ++p) c->dws.plane[p] = (double*)(base + o_plane[p]);
     c->dws.lut = (uint32_t*)(base + o_lut);
     c->dws.lut2 = (uint32_t*)(base + o_lut2);
     c->dws.blk = (KhgBlkInfo*)(base + o_blk);

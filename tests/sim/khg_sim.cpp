@@ -42,7 +42,6 @@ struct SimWs {
         ws.res = alloc<KhgResult>(sizeof(KhgResult));
         KhgDecWorkspaceSizes d;
         khg_dec_workspace_sizes(rows, cols, &d);
-        for (int p = 0; p < 3; ++p) dws.plane[p] = alloc<double>(d.plane[p]);
         dws.lut = alloc<uint32_t>(d.lut);
         dws.lut2 = alloc<uint32_t>(d.lut2);
         dws.blk = alloc<KhgBlkInfo>(d.blk);
