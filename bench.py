@@ -111,8 +111,8 @@ def cpu_baseline(side=5760, frames_per_core=1):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames", type=int, default=128, help="frames per GPU per step")
     ap.add_argument("--streams", type=int, default=24, help="contexts/streams in flight per GPU")
     ap.add_argument("--rows", type=int, default=ROWS)
