@@ -20,6 +20,6 @@ for f in glob.glob("$O/t/**/*kernel_stats.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         dur[r["Name"].split("(")[0][:40]] = float(r["AverageNs"]) / 1e3
 for k in sorted(acc):
-    if "dec_map_kernel<32" in k or "dec_write" in k or "packscan" in k:
+    if "dec_map_kernel<32" in k or "dec_write" in k or "packscan" in k or "inv_kernel" in k or "fwd_kernel" in k:
         print("$1 %-34s %6.1f us" % (k, dur.get(k, 0)), {c: int(acc[k][c] / n[k][c]) for c in sorted(acc[k])})
 PY
