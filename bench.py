@@ -229,7 +229,7 @@ def main():
     # round-trip, so this rate is the one whose small siblings are byte-checked against the reference's files
     square = None
     if not args.no_square:
-        side, SF, SS = 5760, 64, min(16, S)
+        side, SF, SS = 5760, 96, S
         sctx = [khugle_amd.Codec(side, side, device=local_rank) for _ in range(SS)]
         sfr = torch.empty((SF, 3, side, side), dtype=torch.uint8, device=dev)
         for f, g in enumerate(frame_range(rank, world, SF)):
