@@ -278,7 +278,7 @@ def main():
     # longest.  Never part of `value`: the headline configuration is High.
     presets = None
     if not args.no_presets:
-        PF = min(F, 48)
+        PF = min(F, 96)
         presets = {}
         for name, lvl in (("Normal", 0), ("Extreme", 2)):
             plen = [0] * PF
