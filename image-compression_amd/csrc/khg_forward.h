@@ -763,12 +763,13 @@ KHG_DEV void khg_fwd_wg_body(const KhgFwdArgs& a, const KhgFwdPlane* pls, int wg
         // on diagonal u = i + (k - k0) of each band this workgroup emits.
         const int hh = g.ph / 2, hw = g.pw / 2;
         const int nu = KHG_WG_STRIPS * SP + (k1 - k0);
-        for (int e = tid; e < SM::NBAND * nu; e += 256) {
-            int s2 = e / nu, u = e - s2 * nu;
-            int band = LEVEL == 1 ? 4 + s2 : s2;
-            int by = (LEVEL == 1 ? (band >= 5) : (band >= 2)) ? hh : 0;
-            int bx = (LEVEL == 1 ? (band != 5) : (band & 1)) ? hw : 0;
-            sh.rdiv[s2 * SM::RD_N + KHG_RD_PAD + u] = khg_fwd_rdiv_entry(g.q, band, bx + P0 + u, by + k0, a.lvl);
+        KHG_UNROLL
+        for (int s2 = 0; s2 < SM::NBAND; ++s2) {
+            const int band = LEVEL == 1 ? 4 + s2 : s2;
+            const int by = (LEVEL == 1 ? (band >= 5) : (band >= 2)) ? hh : 0;
+            const int bx = (LEVEL == 1 ? (band != 5) : (band & 1)) ? hw : 0;
+            for (int u = tid; u < nu; u += 256)
+                sh.rdiv[s2 * SM::RD_N + KHG_RD_PAD + u] = khg_fwd_rdiv_entry(g.q, band, bx + P0 + u, by + k0, a.lvl);
         }
     }
     KHG_BARRIER();

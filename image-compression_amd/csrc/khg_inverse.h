@@ -188,12 +188,12 @@ KHG_DEV void khg_inv_wg_body(const KhgInvArgs& a, const KhgInvPlane& pl, int wgl
         // Decompress.h:105, 120-121: coefficient = symbol * divisor of its band and position; the divisor depends on
         // the band and on x + y only: pair P0 + i at packed row klo + r sits on diagonal u = i + r.
         const int nu = KHG_WG_STRIPS * KHG_STRIP_PAIRS + 4 + (khi - klo + 1);
-        for (int e = tid; e < SM::NBAND * nu; e += 256) {
-            int s2 = e / nu, u = e - s2 * nu;
-            int band = LEVEL == 1 ? 4 + s2 : s2;
-            int by = (LEVEL == 1 ? (band >= 5) : (band >= 2)) ? hh : 0;
-            int bx = (LEVEL == 1 ? (band != 5) : (band & 1)) ? hw : 0;
-            sh.dv[s2 * KHG_DV_N + u] = khg_divisor(qc, band, bx + P0 + u, by + klo, lvl);
+        KHG_UNROLL
+        for (int s2 = 0; s2 < SM::NBAND; ++s2) {
+            const int band = LEVEL == 1 ? 4 + s2 : s2;
+            const int by = (LEVEL == 1 ? (band >= 5) : (band >= 2)) ? hh : 0;
+            const int bx = (LEVEL == 1 ? (band != 5) : (band & 1)) ? hw : 0;
+            for (int u = tid; u < nu; u += 256) sh.dv[s2 * KHG_DV_N + u] = khg_divisor(qc, band, bx + P0 + u, by + klo, lvl);
         }
     }
     KHG_BARRIER();
@@ -357,10 +357,11 @@ KHG_DEV void khg_istrip_init(KhgInvStrip& st, int slot, const KhgInvGeo& g, int 
 // P0 + i at packed row klo + r sits on diagonal u = i + r.  Inside KHG_FOR_THREADS.
 KHG_DEV void khg_idv_fill(double* dv, const KhgInvGeo& g, const KhgQuant& qc, int lvl, int nu, int tid)
 {
-    for (int e = tid; e < 3 * nu; e += 256) {
-        const int s2 = e / nu, u = e - s2 * nu, band = 4 + s2;
+    KHG_UNROLL
+    for (int s2 = 0; s2 < 3; ++s2) {
+        const int band = 4 + s2;
         const int by = band >= 5 ? g.hh : 0, bx = band != 5 ? g.hw : 0;
-        dv[s2 * KHG_DV_N + u] = khg_divisor(qc, band, bx + g.P0 + u, by + g.klo, lvl);
+        for (int u = tid; u < nu; u += 256) dv[s2 * KHG_DV_N + u] = khg_divisor(qc, band, bx + g.P0 + u, by + g.klo, lvl);
     }
 }
 
